@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the SAT-encode + log-rectilinear-sample hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one pass of the hot path (SATEncoder::EncodeFrameGPU followed
+by SATDecoder::SampleFrameRectGPU, through the C ABI of libf360.so) over this rank's batch of
+synthetic 7680x3840 RGB0 frames, which are resident in HBM before the timed region starts
+(BASELINE.json config "7680x3840 (8K) equirect, full SAT encode -> log-rectilinear decode
+pipeline, batch=64"; each rank owns `--batch` distinct frames, so scaling is weak and there is no
+data-path collective -- RCCL only reduces the final timing).  The metric is input Mpixels/s over
+all ranks.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, timed live with HIP
+events on the stream it runs on) and, at N=1, `cpu_baseline` (the CPU oracle on a bounded sample
+of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def reduced(n):
+    return 16 * math.ceil(n / 1.8 / 16)
+
+
+def lissajous(k):
+    # cx = 0.5 + 0.45 sin(2 pi k / 97), cy = 0.5 + 0.35 sin(2 pi k / 61)
+    return (0.5 + 0.45 * math.sin(2 * math.pi * k / 97), 0.5 + 0.35 * math.sin(2 * math.pi * k / 61))
+
+
+def algorithmic_bytes(w, h, rw, rh):
+    """frame read + SAT write + unique SAT corners read + reduced frame write."""
+    enc = 4 * w * h + 12 * w * h
+    smp = 12 * (rw + 1) * (rh + 1) + 4 * rw * rh
+    return enc, smp
+
+
+def cpu_baseline(w, h, rw, rh, seconds_budget=20.0):
+    """The oracle's SAT encode + sample (kind "port") on the host cores, bounded sample."""
+    import concurrent.futures as cf
+    import oracle_binding as ob
+    ob.lib()
+    # one frame on one thread to size the sample
+    _, t1 = ob.pipeline_encode_sample(1, w, h, rw, rh, 1)
+    cores = max(1, min(16, os.cpu_count() or 1))
+    per_thread = max(1, int(seconds_budget / max(t1, 1e-3) / 1.5))
+    per_thread = min(per_thread, 8)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL during the call
+        futs = [ex.submit(ob.pipeline_encode_sample, per_thread, w, h, rw, rh, 1000 + 100 * i)
+                for i in range(cores)]
+        res = [f.result() for f in futs]
+    wall = time.perf_counter() - t0
+    frames = per_thread * cores
+    busy = sum(r[1] for r in res)
+    return {
+        "value": round(frames * w * h / 1e6 / wall, 2),
+        "unit": "Mpixels/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"{frames} frames {w}x{h} ({per_thread} per thread x {cores} threads), oracle "
+                   f"f360o_sat_encode + f360o_satdec_sample_rect, wall {wall:.1f}s incl. LCG frame "
+                   f"synthesis; 1 thread: {w * h / 1e6 / t1:.1f} Mpixels/s; timed compute "
+                   f"{busy:.1f} core-s"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=3840)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=1, help="contexts (in-order streams) per GPU")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="sample every n-th frame with per-kernel HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="key=value engine option")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                  f"torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no HIP device visible; this benchmark has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import f360_amd as f360  # after torch: share torch's HIP runtime
+    w, h = args.width, args.height
+    rw, rh = reduced(w), reduced(h)
+    B = args.batch
+
+    # ---- synthetic, device-resident inputs: B distinct frames per rank -------------------
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    frames = torch.randint(0, 256, (B, h, w * 4), dtype=torch.uint8, device=dev, generator=gen)
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
+    ctxs = [f360.Context(local_rank, stream=s.cuda_stream) for s in streams]
+    for c in ctxs:
+        for kv in args.opt:
+            k, v = kv.split("=")
+            c.set_option(k, int(v))
+    encs = [f360.SATEncoder(c) for c in ctxs]
+    decs = [f360.SATDecoder(c) for c in ctxs]
+    for d in decs:
+        d.InitializeGrid(rw, rh, w, h)
+    sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev) for _ in ctxs]
+    reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
+    gazes = [lissajous(k) for k in range(B)]
+    frame_ptr = [frames[k].data_ptr() for k in range(B)]
+    red_ptr = [reds[k].data_ptr() for k in range(B)]
+    sat_ptr = [s.data_ptr() for s in sats]
+    torch.cuda.synchronize(dev)
+
+    def step(profile):
+        for k in range(B):
+            s = k % nstreams
+            if profile and k % args.profile_every == 0:
+                ctxs[s].profile_arm(2)  # this frame's encode and sample calls
+            encs[s].EncodeFrameGPU(sat_ptr[s], frame_ptr[k], w, h, 4 * w)
+            decs[s].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[s], (w, h),
+                                       gazes[k][0], gazes[k][1])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if nstreams > 1:  # side streams start after the inputs exist
+        for s in streams[1:]:
+            s.wait_stream(streams[0])
+    for _ in range(args.warmup):
+        step(False)
+    for c in ctxs:
+        c.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    for s in streams:
+        s.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the only collective: RCCL max of the timing
+        elapsed = float(t.item())
+
+    # ---- per-kernel times of the sampled frames (HIP events on the launch stream) --------
+    prof = {}
+    for c in ctxs:
+        for name, (ms, n) in c.profile_read().items():
+            a = prof.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+    kernels = {name: {"avg_us": round(1e3 * ms / n, 2), "launches": n} for name, (ms, n) in prof.items()}
+
+    total_px = float(world) * args.steps * B * w * h
+    value = total_px / 1e6 / elapsed
+    enc_bytes, smp_bytes = algorithmic_bytes(w, h, rw, rh)
+
+    if rank == 0:
+        # dominant kernel: sat_write_kernel.  Its algorithmic bytes per launch: it is the
+        # kernel that produces the table, so it is charged the encode's compulsory traffic
+        # (4 B/px frame read + 12 B/px table write; DESIGN.md "Roofline accounting").
+        dom = "sat_write_kernel"
+        roof = None
+        if dom in kernels:
+            avg_s = kernels[dom]["avg_us"] * 1e-6
+            achieved = enc_bytes / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    with open(tpath) as f:
+                        traffic = json.load(f).get(dom, {}).get(f"{w}x{h}")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": enc_bytes,
+                    "avg_launch_us": kernels[dom]["avg_us"]}
+        path_bytes = enc_bytes + smp_bytes
+        line = {
+            "metric": "Mpixels/s (SAT+log-rectilinear warp), 8K equirect frames",
+            "value": round(value, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"{w}x{h} RGB0 equirect frames, SAT encode -> log-rectilinear "
+                                   f"SAT sample to {rw}x{rh}, batch {B} frames per GPU per step, "
+                                   f"Lissajous gaze, inputs resident in HBM",
+                       "frame": [w, h], "reduced": [rw, rh], "batch_per_gpu": B,
+                       "streams_per_gpu": nstreams, "parallelism": f"frames sharded x{world}"},
+            "roofline": roof,
+            "path_hbm_frac": round(path_bytes * (total_px / (w * h)) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, h, rw, rh)
+        print(json.dumps(line), flush=True)
+
+    for d in decs:
+        d.close()
+    for c in ctxs:
+        c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

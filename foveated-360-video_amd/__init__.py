@@ -1,0 +1,499 @@
+"""foveated-360-video_amd -- MI355X-native frame-transform engine (host side, Python).
+
+Thin ctypes binding over the C ABI of ``include/f360.h`` (``lib/libf360.so``, built
+from ``csrc/`` with hipcc for gfx950).  The classes mirror the reference's C++
+classes for this path -- same method names, argument order and units:
+
+* ``SATEncoder``   -- /root/reference/src/sat_encoder.h:35-42
+* ``SATDecoder``   -- /root/reference/src/sat_decoder.h:44-82
+* ``ImageSampler`` -- /root/reference/src/image_sampler.h:53-101
+* ``Projections``  -- /root/reference/src/projections.h:28-35
+* ``Context``      -- replaces OpenCLManager, /root/reference/src/opencl_manager.h:8-22
+
+Device buffers are plain integers (device addresses: ``DeviceBuffer.ptr`` or
+``torch.Tensor.data_ptr()``), widths/heights are pixels, linesizes are bytes, the
+gaze centre is two floats in [0, 1].
+
+There is no CPU fallback: if ``libf360.so`` is missing, or no HIP device is
+visible, the calls raise.  (The package is imported under its directory name via
+``importlib.import_module("foveated-360-video_amd")`` or the ``f360_amd`` alias
+module at the repository root, because the name contains hyphens.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import (POINTER, byref, c_char_p, c_float, c_int, c_int16, c_size_t,
+                    c_uint8, c_uint32, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libf360.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+F360_OK = 0
+F360_ERR_INVALID_ARG = -1
+F360_ERR_NO_DEVICE = -2
+F360_ERR_HIP = -3
+F360_ERR_OOM = -4
+F360_ERR_NOT_INITIALIZED = -5
+
+
+class F360Error(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"f360 status {status}: {message}")
+        self.status = status
+
+
+def build_native(verbose: bool = False) -> str:
+    """Compile csrc/ into lib/libf360.so (hipcc --offload-arch=gfx950)."""
+    out = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+        print(out.stderr)
+    if out.returncode != 0:
+        raise RuntimeError("building libf360.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/f360.h declares
+_SIGNATURES = {
+    "f360_version": (c_int, []),
+    "f360_last_error_string": (c_char_p, []),
+    "f360_status_string": (c_char_p, [c_int]),
+    "f360_device_count": (c_int, [POINTER(c_int)]),
+    "f360_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "f360_ctx_create_on_stream": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "f360_ctx_destroy": (c_int, [c_void_p]),
+    "f360_ctx_device": (c_int, [c_void_p, POINTER(c_int)]),
+    "f360_ctx_stream": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "f360_sync": (c_int, [c_void_p]),
+    "f360_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "f360_free": (c_int, [c_void_p, c_void_p]),
+    "f360_memset": (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    "f360_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "f360_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "f360_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "f360_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "f360_host_alloc_pinned": (c_int, [c_size_t, POINTER(c_void_p)]),
+    "f360_host_free_pinned": (c_int, [c_void_p]),
+    "f360_event_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "f360_event_destroy": (c_int, [c_void_p]),
+    "f360_event_record": (c_int, [c_void_p, c_void_p]),
+    "f360_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "f360_sat_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "f360_sat_encode_prepare": (c_int, [c_void_p, c_int, c_int]),
+    "f360_satdec_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "f360_satdec_destroy": (c_int, [c_void_p]),
+    "f360_satdec_initialize_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    "f360_satdec_export_grid": (c_int, [c_void_p, c_void_p]),
+    "f360_satdec_sample_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                        c_int, c_int, c_float, c_float]),
+    "f360_satdec_interpolate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
+                                             c_void_p, c_int, c_int, c_int, c_float,
+                                             c_float]),
+    "f360_satdec_decode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int]),
+    "f360_is_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "f360_is_destroy": (c_int, [c_void_p]),
+    "f360_is_initialize_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    "f360_is_initialize_logpolar_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    "f360_is_export_grid": (c_int, [c_void_p, c_void_p]),
+    "f360_is_export_logpolar_grid": (c_int, [c_void_p, c_void_p]),
+    "f360_is_sample_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                    c_int, c_int, c_float, c_float]),
+    "f360_is_sample_logpolar": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                        c_int, c_int, c_int, c_float, c_float]),
+    "f360_is_interpolate_logpolar": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
+                                             c_void_p, c_int, c_int, c_int, c_float,
+                                             c_float]),
+    "f360_is_logpolar_gaussian_blur": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
+                                               c_void_p]),
+    "f360_gnomonic": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                              c_int, c_float, c_float]),
+    "f360_ctx_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "f360_ctx_get_option": (c_int, [c_void_p, c_char_p, POINTER(c_int)]),
+    "f360_kernel_count": (c_int, []),
+    "f360_kernel_name": (c_char_p, [c_int]),
+    "f360_ctx_profile_arm": (c_int, [c_void_p, c_int]),
+    "f360_ctx_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
+    "f360_ctx_profile_reset": (c_int, [c_void_p]),
+    "f360_tables_satdec_grid_axis": (c_int, [c_void_p, c_int, c_int]),
+    "f360_tables_is_grid_axis": (c_int, [c_void_p, c_int, c_int]),
+    "f360_tables_logpolar_axes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "f360_tables_interp_axis": (c_int, [c_void_p, c_int, c_int, c_int]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load libf360.so (once).  Fails loudly when the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with __graft_entry__.build() or "
+            f"`make -C {CSRC_DIR}`; this package has no CPU fallback")
+    handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return handle
+
+
+def _check(status: int) -> None:
+    if status != F360_OK:
+        msg = lib().f360_last_error_string()
+        raise F360Error(status, msg.decode() if msg else "?")
+
+
+def device_count() -> int:
+    n = c_int(0)
+    st = lib().f360_device_count(byref(n))
+    return n.value if st == F360_OK else 0
+
+
+def reduced_size(full: int) -> int:
+    """16 * ceil(full / 1.8 / 16) -- /root/reference/src/run_satlogrectilinear.cc:368-369."""
+    import math
+    return 16 * math.ceil(full / 1.8 / 16)
+
+
+class Context:
+    """Replaces OpenCLManager: device + one in-order stream (opencl_manager.cc:7-67)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = c_void_p()
+        if stream is None:
+            _check(lib().f360_ctx_create(device, byref(self._h)))
+        else:
+            _check(lib().f360_ctx_create_on_stream(device, c_void_p(stream), byref(self._h)))
+        self.device = device
+
+    # OpenCLManager::InitializeContext() analogue for call-sequence parity
+    def InitializeContext(self) -> int:
+        return 0
+
+    @property
+    def handle(self) -> c_void_p:
+        return self._h
+
+    def finish(self) -> None:
+        _check(lib().f360_sync(self._h))
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(lib().f360_ctx_set_option(self._h, key.encode(), value))
+
+    def get_option(self, key: str) -> int:
+        v = c_int(0)
+        _check(lib().f360_ctx_get_option(self._h, key.encode(), byref(v)))
+        return v.value
+
+    def profile_arm(self, calls: int) -> None:
+        """Sample the next `calls` transform calls with HIP events around each kernel."""
+        _check(lib().f360_ctx_profile_arm(self._h, calls))
+
+    def profile_reset(self) -> None:
+        _check(lib().f360_ctx_profile_reset(self._h))
+
+    def profile_read(self) -> dict:
+        """{kernel name: (total_ms, launches)} of the sampled calls since the last reset."""
+        out = {}
+        for k in range(lib().f360_kernel_count()):
+            ms, n = ctypes.c_double(0), c_int(0)
+            _check(lib().f360_ctx_profile_read(self._h, k, byref(ms), byref(n)))
+            if n.value:
+                out[lib().f360_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def malloc(self, nbytes: int) -> "DeviceBuffer":
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, array) -> "DeviceBuffer":
+        import numpy as np
+        a = np.ascontiguousarray(array)
+        buf = DeviceBuffer(self, a.nbytes)
+        buf.copy_from_host(a)
+        return buf
+
+    def close(self) -> None:
+        if self._h:
+            lib().f360_ctx_destroy(self._h)
+            self._h = c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class DeviceBuffer:
+    """cl::Buffer analogue (video_server.cc:224-232): device memory owned by the caller."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = c_void_p()
+        _check(lib().f360_malloc(ctx.handle, self.nbytes, byref(p)))
+        self.ptr = p.value
+
+    def copy_from_host(self, array) -> None:  # cl::copy(queue, begin, end, buffer)
+        import numpy as np
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= self.nbytes
+        _check(lib().f360_memcpy_h2d(self.ctx.handle, c_void_p(self.ptr),
+                                     a.ctypes.data_as(c_void_p), a.nbytes))
+
+    def copy_to_host(self, dtype, shape):  # cl::copy(queue, buffer, begin, end)
+        import numpy as np
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _check(lib().f360_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(c_void_p),
+                                     c_void_p(self.ptr), out.nbytes))
+        return out
+
+    def fill(self, byte: int) -> None:
+        _check(lib().f360_memset(self.ctx.handle, c_void_p(self.ptr), byte, self.nbytes))
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().f360_free(self.ctx.handle, c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __int__(self) -> int:
+        return self.ptr
+
+
+class Event:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = c_void_p()
+        _check(lib().f360_event_create(ctx.handle, byref(self._h)))
+
+    def record(self) -> None:
+        _check(lib().f360_event_record(self.ctx.handle, self._h))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = c_float(0)
+        _check(lib().f360_event_elapsed_ms(self._h, stop._h, byref(ms)))
+        return ms.value
+
+    def destroy(self) -> None:
+        if self._h:
+            lib().f360_event_destroy(self._h)
+            self._h = c_void_p()
+
+
+def _p(x) -> c_void_p:
+    return c_void_p(int(x))
+
+
+class SATEncoder:
+    """sat_encoder.h:35-42.  ``SATEncoder()`` without a context is the CPU-only object of
+    the reference (sat_encoder.cc:3): its GPU method reports and returns."""
+
+    def __init__(self, cl_manager: Context | None = None):
+        self.cl_manager = cl_manager
+
+    def EncodeFrameGPU(self, cl_target_buffer, cl_source_buffer, source_width: int,
+                       source_height: int, source_linesize: int) -> None:
+        if self.cl_manager is None:
+            raise F360Error(F360_ERR_NOT_INITIALIZED,
+                            "[SATEncoder::EncodeFrameGPU] Not initialized with a device context")
+        _check(lib().f360_sat_encode(self.cl_manager.handle, _p(cl_target_buffer),
+                                     _p(cl_source_buffer), source_width, source_height,
+                                     source_linesize))
+
+
+class SATDecoder:
+    """sat_decoder.h:44-82 (device methods)."""
+
+    def __init__(self, cl_manager: Context | None = None):
+        self.cl_manager = cl_manager
+        self._h = c_void_p()
+        if cl_manager is not None:
+            _check(lib().f360_satdec_create(cl_manager.handle, byref(self._h)))
+
+    def _need(self, what: str) -> None:
+        if self.cl_manager is None:
+            raise F360Error(F360_ERR_NOT_INITIALIZED,
+                            f"[SATDecoder::{what}] Not initialized with a device context")
+
+    def InitializeGrid(self, target_width, target_height, source_width, source_height) -> None:
+        self._need("InitializeGrid")
+        _check(lib().f360_satdec_initialize_grid(self._h, target_width, target_height,
+                                                 source_width, source_height))
+
+    def export_grid(self, target_width, target_height):
+        import numpy as np
+        g = np.empty((target_height + 1, target_width + 1, 2), dtype=np.int16)
+        _check(lib().f360_satdec_export_grid(self._h, g.ctypes.data_as(c_void_p)))
+        return g
+
+    def SampleFrameRectGPU(self, cl_target_buffer, target_width, target_height,
+                           target_linesize, cl_source_buffer, codec_ctx, center_x,
+                           center_y) -> None:
+        """``codec_ctx`` is anything with ``.width``/``.height`` (or a (w, h) tuple): the
+        reference reads only those two fields (sat_decoder.cc:328-329)."""
+        self._need("SampleFrameRectGPU")
+        w, h = (codec_ctx if isinstance(codec_ctx, tuple)
+                else (codec_ctx.width, codec_ctx.height))
+        _check(lib().f360_satdec_sample_rect(self._h, _p(cl_target_buffer), target_width,
+                                             target_height, target_linesize,
+                                             _p(cl_source_buffer), w, h, center_x, center_y))
+
+    def InterpolateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
+                                target_linesize, cl_source_buffer, source_width,
+                                source_height, source_linesize, center_x, center_y) -> None:
+        self._need("InterpolateFrameRectGPU")
+        _check(lib().f360_satdec_interpolate_rect(self._h, _p(cl_target_buffer), target_width,
+                                                  target_height, target_linesize,
+                                                  _p(cl_source_buffer), source_width,
+                                                  source_height, source_linesize, center_x,
+                                                  center_y))
+
+    def DecodeFrameGPU(self, cl_target_buffer, target_linesize, cl_source_buffer, width,
+                       height) -> None:
+        self._need("DecodeFrameGPU")
+        _check(lib().f360_satdec_decode(self._h, _p(cl_target_buffer), target_linesize,
+                                        _p(cl_source_buffer), width, height))
+
+    def close(self) -> None:
+        if self._h:
+            lib().f360_satdec_destroy(self._h)
+            self._h = c_void_p()
+
+
+class ImageSampler:
+    """image_sampler.h:53-101 (device methods; the image-pyramid pair has no kernel source
+    in the reference and is out of scope)."""
+
+    def __init__(self, cl_manager: Context | None = None):
+        self.cl_manager = cl_manager
+        self._h = c_void_p()
+        if cl_manager is not None:
+            _check(lib().f360_is_create(cl_manager.handle, byref(self._h)))
+
+    def _need(self, what: str) -> None:
+        if self.cl_manager is None:
+            raise F360Error(F360_ERR_NOT_INITIALIZED,
+                            f"[ImageSampler::{what}] Not initialized with a device context")
+
+    def InitializeGrid(self, target_width, target_height, source_width, source_height) -> None:
+        self._need("InitializeGrid")
+        _check(lib().f360_is_initialize_grid(self._h, target_width, target_height,
+                                             source_width, source_height))
+
+    def InitializeLogpolarGrid(self, target_width, target_height, source_width,
+                               source_height) -> None:
+        self._need("InitializeLogpolarGrid")
+        _check(lib().f360_is_initialize_logpolar_grid(self._h, target_width, target_height,
+                                                      source_width, source_height))
+
+    def export_grid(self, target_width, target_height):
+        import numpy as np
+        g = np.empty((target_height, target_width, 2), dtype=np.int16)
+        _check(lib().f360_is_export_grid(self._h, g.ctypes.data_as(c_void_p)))
+        return g
+
+    def export_logpolar_grid(self, target_width, target_height):
+        import numpy as np
+        g = np.empty((target_height, target_width, 2), dtype=np.int16)
+        _check(lib().f360_is_export_logpolar_grid(self._h, g.ctypes.data_as(c_void_p)))
+        return g
+
+    def SampleFrameRectGPU(self, cl_target_buffer, target_width, target_height,
+                           target_linesize, cl_source_buffer, source_width, source_height,
+                           source_linesize, center_x, center_y) -> None:
+        self._need("SampleFrameRectGPU")
+        _check(lib().f360_is_sample_rect(self._h, _p(cl_target_buffer), target_width,
+                                         target_height, target_linesize, _p(cl_source_buffer),
+                                         source_width, source_height, source_linesize,
+                                         center_x, center_y))
+
+    def SampleFrameLogPolarGPU(self, cl_target_buffer, target_width, target_height,
+                               target_linesize, cl_source_buffer, source_width,
+                               source_height, source_linesize, center_x, center_y) -> None:
+        self._need("SampleFrameLogPolarGPU")
+        _check(lib().f360_is_sample_logpolar(self._h, _p(cl_target_buffer), target_width,
+                                             target_height, target_linesize,
+                                             _p(cl_source_buffer), source_width, source_height,
+                                             source_linesize, center_x, center_y))
+
+    def InterpolateFrameLogPolarGPU(self, cl_target_buffer, target_width, target_height,
+                                    target_linesize, cl_source_buffer, source_width,
+                                    source_height, source_linesize, center_x,
+                                    center_y) -> None:
+        self._need("InterpolateFrameLogPolarGPU")
+        _check(lib().f360_is_interpolate_logpolar(self._h, _p(cl_target_buffer), target_width,
+                                                  target_height, target_linesize,
+                                                  _p(cl_source_buffer), source_width,
+                                                  source_height, source_linesize, center_x,
+                                                  center_y))
+
+    def ApplyLogPolarGaussianBlur(self, cl_target_buffer, target_width, target_height,
+                                  target_linesize, cl_source_buffer) -> None:
+        self._need("ApplyLogPolarGaussianBlur")
+        _check(lib().f360_is_logpolar_gaussian_blur(self._h, _p(cl_target_buffer),
+                                                    target_width, target_height,
+                                                    target_linesize, _p(cl_source_buffer)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().f360_is_destroy(self._h)
+            self._h = c_void_p()
+
+
+class Projections:
+    """projections.h:28-35.  Positional order follows projections.cc:51-55
+    (target_width before target_height; the header swaps the two *names*)."""
+
+    def __init__(self, cl_manager: Context):
+        self.cl_manager = cl_manager
+
+    def GnomonicProjection(self, cl_target_buffer, target_width, target_height,
+                           target_linesize, cl_source_buffer, source_width, source_height,
+                           source_linesize, center_x, center_y) -> None:
+        _check(lib().f360_gnomonic(self.cl_manager.handle, _p(cl_target_buffer), target_width,
+                                   target_height, target_linesize, _p(cl_source_buffer),
+                                   source_width, source_height, source_linesize, center_x,
+                                   center_y))
+
+
+# ---- host-only table builders (no device needed; used by the CPU test tier) ----
+def tables_satdec_grid_axis(n_out: int, n_src: int):
+    import numpy as np
+    g = np.empty(n_out + 1, dtype=np.int16)
+    _check(lib().f360_tables_satdec_grid_axis(g.ctypes.data_as(c_void_p), n_out, n_src))
+    return g
+
+
+def tables_is_grid_axis(n_out: int, n_src: int):
+    import numpy as np
+    g = np.empty(n_out, dtype=np.int16)
+    _check(lib().f360_tables_is_grid_axis(g.ctypes.data_as(c_void_p), n_out, n_src))
+    return g
+
+
+def tables_logpolar_axes(out_w: int, out_h: int):
+    import numpy as np
+    r = np.empty(out_w, dtype=np.float32)
+    c = np.empty(out_h, dtype=np.float32)
+    s = np.empty(out_h, dtype=np.float32)
+    _check(lib().f360_tables_logpolar_axes(r.ctypes.data_as(c_void_p),
+                                           c.ctypes.data_as(c_void_p),
+                                           s.ctypes.data_as(c_void_p), out_w, out_h))
+    return r, c, s
+
+
+def tables_interp_axis(value_range: int, n_full: int, n_reduced: int):
+    import numpy as np
+    t = np.empty((2 * value_range + 1, 4), dtype=np.int32)
+    _check(lib().f360_tables_interp_axis(t.ctypes.data_as(c_void_p), value_range, n_full,
+                                         n_reduced))
+    return t

@@ -1,0 +1,173 @@
+// f360_internal.h -- shared declarations of the HIP engine behind include/f360.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "f360.h"
+
+namespace f360 {
+
+void set_error(const char *fmt, ...);
+
+#define F360_HIP_TRY(expr)                                                     \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      ::f360::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                   \
+      return _e == hipErrorOutOfMemory ? F360_ERR_OOM : F360_ERR_HIP;          \
+    }                                                                          \
+  } while (0)
+
+#define F360_REQUIRE(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::f360::set_error(__VA_ARGS__);    \
+      return F360_ERR_INVALID_ARG;       \
+    }                                    \
+  } while (0)
+
+// A device allocation owned by an engine object.
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t n);  // grows (never shrinks); contents undefined after growth
+  void release();
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Scratch of the SAT encoder for one frame geometry (see sat_encode.hip).
+struct SatEncodePlan {
+  int width = 0, height = 0;
+  int band_rows = 0;   // TH: rows per band (tile height of the writer kernel)
+  int sb_bands = 0;    // bands per super-band (tile height of the reducer)
+  int nstrips = 0, nbands = 0, nsb = 0;
+  int wp3 = 0;         // 3 * padded width (padded to whole 256-pixel strips)
+  DevBuf ws;           // one allocation, carved below
+  uint32_t *lp = nullptr;        // [nbands][wp3]  column sums above the band, inside its super-band
+  uint32_t *sbtotal = nullptr;   // [nsb][wp3]     column sums of each super-band
+  uint32_t *sbprefix = nullptr;  // [nsb][wp3]     column sums of all super-bands above
+  uint32_t *rowsum = nullptr;    // [nstrips][height][3]
+  uint32_t *rowcarry = nullptr;  // [nstrips][height][3] sum of the strips to the left
+  uint32_t *tiletotal = nullptr; // [nstrips][nbands][3]
+  uint32_t *tprefix = nullptr;   // [nstrips][nbands][3] sum of the tiles to the left
+};
+
+}  // namespace f360
+
+namespace f360 {
+// Kernel ids of the per-kernel timing facility (f360_ctx_profile_*).
+enum KernelId {
+  kSatReduce = 0,
+  kSatCarry,
+  kSatWrite,
+  kSampleRect,
+  kInterpolateRect,
+  kSatDecode,
+  kIsSampleRect,
+  kIsSampleLogpolar,
+  kIsInterpolateLogpolar,
+  kIsBlur,
+  kGnomonic,
+  kKernelCount
+};
+struct ProfSpan {
+  int kid;
+  hipEvent_t a, b;
+};
+}  // namespace f360
+
+struct f360_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  f360::SatEncodePlan enc;
+  // options (f360_ctx_set_option)
+  int opt_band_rows = 32;      // "sat.band_rows": 16 | 32 | 64
+  int opt_sb_bands = 8;        // "sat.sb_bands"
+  int opt_store_mode = 0;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-transposed
+  int opt_sample_variant = 0;  // "sample.variant": 0 per-pixel, 1 column walker
+  int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
+  // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
+  int prof_armed = 0;
+  std::vector<f360::ProfSpan> prof_pending;
+  std::vector<hipEvent_t> prof_free;
+  double prof_ms[f360::kKernelCount] = {};
+  int prof_launches[f360::kKernelCount] = {};
+};
+
+namespace f360 {
+// Brackets one kernel launch with HIP events on the context's stream when the
+// current call is being sampled.
+class KernelSpan {
+ public:
+  KernelSpan(f360_ctx *ctx, int kid, bool on) : ctx_(ctx), kid_(kid), on_(on) {
+    if (!on_) return;
+    a_ = take();
+    b_ = take();
+    if (!a_ || !b_) { on_ = false; return; }
+    (void)hipEventRecord(a_, ctx_->stream);
+  }
+  ~KernelSpan() {
+    if (!on_) return;
+    (void)hipEventRecord(b_, ctx_->stream);
+    ctx_->prof_pending.push_back(ProfSpan{kid_, a_, b_});
+  }
+ private:
+  hipEvent_t take() {
+    if (!ctx_->prof_free.empty()) {
+      hipEvent_t e = ctx_->prof_free.back();
+      ctx_->prof_free.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  f360_ctx *ctx_;
+  int kid_;
+  bool on_;
+  hipEvent_t a_ = nullptr, b_ = nullptr;
+};
+// true when this call is sampled; consumes one armed call
+inline bool take_profile_slot(f360_ctx *ctx) {
+  if (ctx->prof_armed <= 0) return false;
+  --ctx->prof_armed;
+  return true;
+}
+}  // namespace f360
+
+struct f360_event {
+  hipEvent_t ev = nullptr;
+};
+
+struct f360_sat_decoder {
+  f360_ctx *ctx = nullptr;
+  // log-rectilinear midpoint grid, 1-D factors (create_grid_kernel is separable)
+  int gw = 0, gh = 0, sw = 0, sh = 0;  // target / source geometry of the grid
+  std::vector<int16_t> gx_host, gy_host;  // gw+1 / gh+1 entries
+  f360::DevBuf gx_dev, gy_dev;
+  // inverse-map tables of the interpolate kernel, indexed by pixel offset from
+  // the gaze centre (geometry-only; see sat_decoder.hip)
+  int it_w = 0, it_h = 0, it_rw = 0, it_rh = 0;  // geometry they were built for
+  int it_dx = 0, it_dy = 0;                      // covered offset range [-d, d]
+  f360::DevBuf itx_dev, ity_dev;
+};
+
+struct f360_image_sampler {
+  f360_ctx *ctx = nullptr;
+  int gw = 0, gh = 0, sw = 0, sh = 0;
+  std::vector<int16_t> gx_host, gy_host;  // gw / gh entries
+  f360::DevBuf gx_dev, gy_dev;
+  int lw = 0, lh = 0, lsw = 0, lsh = 0;   // log-polar grid geometry
+  std::vector<float> lrad_host, lcos_host, lsin_host;
+  f360::DevBuf lrad_dev, lcos_dev, lsin_dev;
+  // interpolate_logpolar tables (per source geometry)
+  int iw = 0, ih = 0;
+  f360::DevBuf irad_dev, icos_dev, isin_dev;  // float[iw], double[ih], double[ih]
+};

@@ -1,0 +1,434 @@
+// image_sampler.hip -- ImageSampler device side: point-sampled log-rectilinear
+// warp, log-polar forward warp, log-polar bilinear un-warp, 3x3 blur.
+//
+// Replaces ImageSampler::{InitializeGrid, InitializeLogpolarGrid,
+// SampleFrameRectGPU, SampleFrameLogPolarGPU, InterpolateFrameLogPolarGPU,
+// ApplyLogPolarGaussianBlur} (src/image_sampler.cc:170-299,577-621,780-857) and
+// their kernels (src/image_sampler_sample_rect_kernel.cl,
+// src/image_sampler_sample_logpolar_kernel.cl,
+// src/image_sampler_interpolate_kernel.cl).
+#include <cmath>
+
+#include "f360_internal.h"
+#include "host_tables.h"
+
+namespace {
+
+// OpenCL float builtins as correctly rounded floats (DESIGN.md "Float model").
+__device__ __forceinline__ float cr_logf(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float cr_atanf(float x) { return (float)atan((double)x); }
+
+__device__ __forceinline__ float mixf(float a, float b, float t) {
+  return a + (b - a) * t;
+}
+
+__device__ __forceinline__ void copy_rgb(uint8_t *o, const uint8_t *s) {
+  o[0] = s[0];
+  o[1] = s[1];
+  o[2] = s[2];
+}
+
+// sample_rect_kernel, src/image_sampler_sample_rect_kernel.cl:1-46
+__global__ __launch_bounds__(256) void is_sample_rect_kernel(
+    uint8_t *__restrict__ dst, int out_w, int out_h, int out_linesize, int obpp,
+    const uint8_t *__restrict__ src, int src_w, int src_h, int src_linesize,
+    int sbpp, const int16_t *__restrict__ gx, const int16_t *__restrict__ gy,
+    float cxf, float cyf) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= out_w || j >= out_h) return;
+  int xp = (int)(cxf + (float)gx[i]);  // float add, then truncation (:24-25)
+  const int yp = (int)(cyf + (float)gy[j]);
+  if (xp >= src_w)
+    xp -= src_w;
+  else if (xp < 0)
+    xp += src_w;
+  if (xp >= 0 && xp < src_w && yp >= 0 && yp < src_h)
+    copy_rgb(dst + (size_t)j * out_linesize + (size_t)i * obpp,
+             src + (size_t)yp * src_linesize + (size_t)xp * sbpp);
+}
+
+// sample_logpolar_kernel, src/image_sampler_sample_logpolar_kernel.cl:41-86,
+// with the grid of :5-39 recomputed from its separable factors:
+// grid.x = (short)(int)(radius[i] * cos[j]), grid.y likewise with sin.
+__global__ __launch_bounds__(256) void is_sample_logpolar_kernel(
+    uint8_t *__restrict__ dst, int out_w, int out_h, int out_linesize, int obpp,
+    const uint8_t *__restrict__ src, int src_w, int src_h, int src_linesize,
+    int sbpp, const float *__restrict__ rad, const float *__restrict__ cs,
+    const float *__restrict__ sn, float cxf, float cyf) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= out_w || j >= out_h) return;
+  const float r = rad[i];
+  const int gxv = (int)(int16_t)(int)(r * cs[j]);
+  const int gyv = (int)(int16_t)(int)(r * sn[j]);
+  int xp = (int)(cxf + (float)gxv);
+  int yp = (int)(cyf + (float)gyv);
+  xp = (xp + 10 * src_w) % src_w;
+  yp = min(max(yp, 0), src_h - 1);
+  if (xp >= 0 && xp < src_w && yp >= 0 && yp < src_h)
+    copy_rgb(dst + (size_t)j * out_linesize + (size_t)i * obpp,
+             src + (size_t)yp * src_linesize + (size_t)xp * sbpp);
+}
+
+// interpolate_logpolar_kernel, src/image_sampler_interpolate_kernel.cl:1-81
+__global__ __launch_bounds__(256) void is_interpolate_logpolar_kernel(
+    uint32_t *__restrict__ dst, int out_w, int out_h,
+    const uint32_t *__restrict__ src, int src_w, int src_h,
+    const float *__restrict__ rad, const double *__restrict__ cs,
+    const double *__restrict__ sn, float cxf, float cyf, int cxp, int cyp) {
+  const int x0 = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x0 >= out_w || y >= out_h) return;
+  const int rw = src_w, rh = src_h;
+  int x = x0;
+  if (x - cxp > out_w / 2)
+    x -= out_w;
+  else if (x - cxp < (-out_w) / 2)
+    x += out_w;
+  const int dx = x - cxp, dy = y - cyp;
+  float i_f = 0.0f;
+  if (dx != 0 || dy != 0) {
+    // pow(d, 2.0f) correctly rounded == one rounding of the exact product;
+    // pow(v, 1.0f) == v
+    const float fx = (float)dx, fy = (float)dy;
+    const float r2 = fx * fx + fy * fy;
+    i_f = (float)rw * (cr_logf(sqrtf(r2)) / 10.0f);
+  }
+  const int i = min(max((int)roundf(i_f), 0), rw - 1);
+  float j_f;
+  if (dx != 0) {
+    j_f = (float)(((double)cr_atanf((float)dy / (float)dx) +
+                   M_PI * (double)(dx < 0)) *
+                  ((double)(float)rh / (2.0 * M_PI)));
+    j_f = fmodf(j_f + (float)(2 * rh), (float)src_h);
+  } else {
+    j_f = (float)((M_PI_2 + M_PI * (double)(dy < 0)) *
+                  ((double)rh / (2.0 * M_PI)));
+  }
+  const int j = min(max((int)roundf(j_f), 0), rh - 1);
+  const double radius = (double)rad[i];
+  const int calc_x = (int)((double)cxf + radius * cs[j]);
+  const int calc_y = (int)((double)cyf + radius * sn[j]);
+  uint32_t out;
+  if (calc_x == x && calc_y == y) {
+    out = src[(size_t)j * src_w + i] & 0x00ffffffu;
+  } else {
+    const int min_i = min(max((int)floorf(i_f), 0), src_w - 1);
+    const int min_j = (int)floorf(j_f + (float)src_h) % src_h;
+    const int max_i = min(max((int)ceilf(i_f), 0), src_w - 1);
+    const int max_j = (int)ceilf(j_f + (float)src_h) % src_h;
+    const uint32_t tl = src[(size_t)min_j * src_w + min_i];
+    const uint32_t tr = src[(size_t)min_j * src_w + max_i];
+    const uint32_t bl = src[(size_t)max_j * src_w + min_i];
+    const uint32_t br = src[(size_t)max_j * src_w + max_i];
+    const float ir = i_f - floorf(i_f), jr = j_f - floorf(j_f);
+    out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float l = mixf((float)((tl >> (8 * c)) & 0xffu), (float)((bl >> (8 * c)) & 0xffu), jr);
+      const float r = mixf((float)((tr >> (8 * c)) & 0xffu), (float)((br >> (8 * c)) & 0xffu), jr);
+      out |= ((uint32_t)(int)mixf(l, r, ir) & 0xffu) << (8 * c);
+    }
+  }
+  dst[(size_t)y * out_w + x0] = out;
+}
+
+// logpolar_gaussian_blur_kernel, src/image_sampler_sample_logpolar_kernel.cl:88-142
+__global__ __launch_bounds__(256) void is_blur_kernel(uint32_t *__restrict__ dst,
+                                                      int w, int h,
+                                                      const uint32_t *__restrict__ src) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= w || j >= h) return;
+  if (i < w / 2) {
+    dst[(size_t)j * w + i] = src[(size_t)j * w + i] & 0x00ffffffu;
+    return;
+  }
+  const float P1 = (float)0.3377, P2 = (float)0.1217, P3 = (float)0.0439;
+  const int jm = max(j - 1, 0), jp = min(j + 1, h - 1);
+  const int im = max(i - 1, 0), ip = min(i + 1, w - 1);
+  const uint32_t t11 = src[(size_t)jm * w + im], t12 = src[(size_t)jm * w + i],
+                 t13 = src[(size_t)jm * w + ip], t21 = src[(size_t)j * w + im],
+                 t22 = src[(size_t)j * w + i], t23 = src[(size_t)j * w + ip],
+                 t31 = src[(size_t)jp * w + im], t32 = src[(size_t)jp * w + i],
+                 t33 = src[(size_t)jp * w + ip];
+  uint32_t out = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#define F360_CH(t) ((float)(((t) >> (8 * c)) & 0xffu))
+    const float corners = F360_CH(t11) + F360_CH(t13) + F360_CH(t31) + F360_CH(t33);
+    const float edges = F360_CH(t12) + F360_CH(t21) + F360_CH(t23) + F360_CH(t32);
+    const float v = P3 * corners + P2 * edges + P1 * F360_CH(t22);
+#undef F360_CH
+    out |= ((uint32_t)(int)v & 0xffu) << (8 * c);
+  }
+  dst[(size_t)j * w + i] = out;
+}
+
+int upload(f360_ctx *ctx, f360::DevBuf &buf, const void *host, size_t bytes) {
+  F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int st = buf.reserve(bytes);
+  if (st != F360_OK) return st;
+  F360_HIP_TRY(hipMemcpy(buf.p, host, bytes, hipMemcpyHostToDevice));
+  return F360_OK;
+}
+
+bool bad_centre(float c) { return !(std::fabs(c) <= 16.0f); }
+
+}  // namespace
+
+extern "C" {
+
+int f360_is_create(f360_ctx *ctx, f360_image_sampler **out) {
+  F360_REQUIRE(ctx && out, "f360_is_create: null argument");
+  f360_image_sampler *s = new f360_image_sampler();
+  s->ctx = ctx;
+  *out = s;
+  return F360_OK;
+}
+
+int f360_is_destroy(f360_image_sampler *is) {
+  if (!is) return F360_OK;
+  (void)hipStreamSynchronize(is->ctx->stream);
+  is->gx_dev.release();
+  is->gy_dev.release();
+  is->lrad_dev.release();
+  is->lcos_dev.release();
+  is->lsin_dev.release();
+  is->irad_dev.release();
+  is->icos_dev.release();
+  is->isin_dev.release();
+  delete is;
+  return F360_OK;
+}
+
+int f360_is_initialize_grid(f360_image_sampler *is, int target_width,
+                            int target_height, int source_width,
+                            int source_height) {
+  F360_REQUIRE(is, "f360_is_initialize_grid: null sampler");
+  F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 1 &&
+                   source_height >= 1,
+               "f360_is_initialize_grid: bad geometry");
+  if (is->gw == target_width && is->gh == target_height && is->sw == source_width &&
+      is->sh == source_height && is->gx_dev.p)
+    return F360_OK;
+  F360_HIP_TRY(hipSetDevice(is->ctx->device));
+  f360::build_is_grid_axis(is->gx_host, target_width, source_width);
+  f360::build_is_grid_axis(is->gy_host, target_height, source_height);
+  int st = upload(is->ctx, is->gx_dev, is->gx_host.data(),
+                  is->gx_host.size() * sizeof(int16_t));
+  if (st != F360_OK) return st;
+  st = upload(is->ctx, is->gy_dev, is->gy_host.data(),
+              is->gy_host.size() * sizeof(int16_t));
+  if (st != F360_OK) return st;
+  is->gw = target_width;
+  is->gh = target_height;
+  is->sw = source_width;
+  is->sh = source_height;
+  return F360_OK;
+}
+
+int f360_is_initialize_logpolar_grid(f360_image_sampler *is, int target_width,
+                                     int target_height, int source_width,
+                                     int source_height) {
+  F360_REQUIRE(is, "f360_is_initialize_logpolar_grid: null sampler");
+  F360_REQUIRE(target_width >= 1 && target_height >= 1,
+               "f360_is_initialize_logpolar_grid: bad geometry");
+  if (is->lw == target_width && is->lh == target_height && is->lrad_dev.p) {
+    is->lsw = source_width;
+    is->lsh = source_height;
+    return F360_OK;
+  }
+  F360_HIP_TRY(hipSetDevice(is->ctx->device));
+  f360::build_logpolar_axes(is->lrad_host, is->lcos_host, is->lsin_host,
+                            target_width, target_height);
+  int st = upload(is->ctx, is->lrad_dev, is->lrad_host.data(),
+                  is->lrad_host.size() * sizeof(float));
+  if (st != F360_OK) return st;
+  st = upload(is->ctx, is->lcos_dev, is->lcos_host.data(),
+              is->lcos_host.size() * sizeof(float));
+  if (st != F360_OK) return st;
+  st = upload(is->ctx, is->lsin_dev, is->lsin_host.data(),
+              is->lsin_host.size() * sizeof(float));
+  if (st != F360_OK) return st;
+  is->lw = target_width;
+  is->lh = target_height;
+  is->lsw = source_width;
+  is->lsh = source_height;
+  return F360_OK;
+}
+
+int f360_is_export_grid(f360_image_sampler *is, int16_t *grid_host) {
+  F360_REQUIRE(is && grid_host, "f360_is_export_grid: null argument");
+  if (!is->gx_dev.p) {
+    f360::set_error("f360_is_export_grid: grid not initialised");
+    return F360_ERR_NOT_INITIALIZED;
+  }
+  std::vector<int16_t> gx(is->gx_host.size()), gy(is->gy_host.size());
+  F360_HIP_TRY(hipStreamSynchronize(is->ctx->stream));
+  F360_HIP_TRY(hipMemcpy(gx.data(), is->gx_dev.p, gx.size() * sizeof(int16_t),
+                         hipMemcpyDeviceToHost));
+  F360_HIP_TRY(hipMemcpy(gy.data(), is->gy_dev.p, gy.size() * sizeof(int16_t),
+                         hipMemcpyDeviceToHost));
+  for (int j = 0; j < is->gh; ++j)
+    for (int i = 0; i < is->gw; ++i) {
+      grid_host[((size_t)j * is->gw + i) * 2 + 0] = gx[(size_t)i];
+      grid_host[((size_t)j * is->gw + i) * 2 + 1] = gy[(size_t)j];
+    }
+  return F360_OK;
+}
+
+int f360_is_export_logpolar_grid(f360_image_sampler *is, int16_t *grid_host) {
+  F360_REQUIRE(is && grid_host, "f360_is_export_logpolar_grid: null argument");
+  if (!is->lrad_dev.p) {
+    f360::set_error("f360_is_export_logpolar_grid: grid not initialised");
+    return F360_ERR_NOT_INITIALIZED;
+  }
+  std::vector<float> rad(is->lrad_host.size()), cs(is->lcos_host.size()),
+      sn(is->lsin_host.size());
+  F360_HIP_TRY(hipStreamSynchronize(is->ctx->stream));
+  F360_HIP_TRY(hipMemcpy(rad.data(), is->lrad_dev.p, rad.size() * sizeof(float),
+                         hipMemcpyDeviceToHost));
+  F360_HIP_TRY(hipMemcpy(cs.data(), is->lcos_dev.p, cs.size() * sizeof(float),
+                         hipMemcpyDeviceToHost));
+  F360_HIP_TRY(hipMemcpy(sn.data(), is->lsin_dev.p, sn.size() * sizeof(float),
+                         hipMemcpyDeviceToHost));
+  for (int j = 0; j < is->lh; ++j)
+    for (int i = 0; i < is->lw; ++i) {
+      grid_host[((size_t)j * is->lw + i) * 2 + 0] =
+          (int16_t)(int)(rad[(size_t)i] * cs[(size_t)j]);
+      grid_host[((size_t)j * is->lw + i) * 2 + 1] =
+          (int16_t)(int)(rad[(size_t)i] * sn[(size_t)j]);
+    }
+  return F360_OK;
+}
+
+int f360_is_sample_rect(f360_image_sampler *is, uint8_t *target_dev,
+                        int target_width, int target_height,
+                        int target_linesize, const uint8_t *source_dev,
+                        int source_width, int source_height,
+                        int source_linesize, float center_x, float center_y) {
+  F360_REQUIRE(is, "f360_is_sample_rect: null sampler");
+  F360_REQUIRE(target_dev && source_dev, "f360_is_sample_rect: null buffer");
+  if (!is->gx_dev.p) {  // the reference never auto-initialises (image_sampler.cc:261)
+    f360::set_error("f360_is_sample_rect: InitializeGrid has not been called");
+    return F360_ERR_NOT_INITIALIZED;
+  }
+  F360_REQUIRE(is->gw == target_width && is->gh == target_height,
+               "f360_is_sample_rect: grid was initialised for %dx%d", is->gw, is->gh);
+  F360_REQUIRE(target_linesize / target_width >= 3 &&
+                   source_linesize / source_width >= 3,
+               "f360_is_sample_rect: need >= 3 bytes per pixel");
+  F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),
+               "f360_is_sample_rect: gaze centre out of range");
+  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  hipLaunchKernelGGL(is_sample_rect_kernel, grid, dim3(256), 0, is->ctx->stream,
+                     target_dev, target_width, target_height, target_linesize,
+                     target_linesize / target_width, source_dev, source_width,
+                     source_height, source_linesize, source_linesize / source_width,
+                     is->gx_dev.as<int16_t>(), is->gy_dev.as<int16_t>(),
+                     center_x * (float)source_width,
+                     center_y * (float)source_height);
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+int f360_is_sample_logpolar(f360_image_sampler *is, uint8_t *target_dev,
+                            int target_width, int target_height,
+                            int target_linesize, const uint8_t *source_dev,
+                            int source_width, int source_height,
+                            int source_linesize, float center_x,
+                            float center_y) {
+  F360_REQUIRE(is, "f360_is_sample_logpolar: null sampler");
+  F360_REQUIRE(target_dev && source_dev, "f360_is_sample_logpolar: null buffer");
+  if (!is->lrad_dev.p) {
+    f360::set_error(
+        "f360_is_sample_logpolar: InitializeLogpolarGrid has not been called");
+    return F360_ERR_NOT_INITIALIZED;
+  }
+  F360_REQUIRE(is->lw == target_width && is->lh == target_height,
+               "f360_is_sample_logpolar: grid was initialised for %dx%d", is->lw,
+               is->lh);
+  F360_REQUIRE(target_linesize / target_width >= 3 &&
+                   source_linesize / source_width >= 3,
+               "f360_is_sample_logpolar: need >= 3 bytes per pixel");
+  F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),
+               "f360_is_sample_logpolar: gaze centre out of range");
+  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  hipLaunchKernelGGL(is_sample_logpolar_kernel, grid, dim3(256), 0, is->ctx->stream,
+                     target_dev, target_width, target_height, target_linesize,
+                     target_linesize / target_width, source_dev, source_width,
+                     source_height, source_linesize, source_linesize / source_width,
+                     is->lrad_dev.as<float>(), is->lcos_dev.as<float>(),
+                     is->lsin_dev.as<float>(), center_x * (float)source_width,
+                     center_y * (float)source_height);
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
+                                 int target_width, int target_height,
+                                 int target_linesize, const uint8_t *source_dev,
+                                 int source_width, int source_height,
+                                 int source_linesize, float center_x,
+                                 float center_y) {
+  (void)target_linesize;
+  (void)source_linesize;
+  F360_REQUIRE(is, "f360_is_interpolate_logpolar: null sampler");
+  F360_REQUIRE(target_dev && source_dev, "f360_is_interpolate_logpolar: null buffer");
+  F360_REQUIRE(target_width >= 2 && target_height >= 2 && source_width >= 1 &&
+                   source_height >= 1,
+               "f360_is_interpolate_logpolar: bad geometry");
+  F360_REQUIRE(((uintptr_t)target_dev % 4) == 0 && ((uintptr_t)source_dev % 4) == 0,
+               "f360_is_interpolate_logpolar: buffers must be 4-byte aligned");
+  F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),
+               "f360_is_interpolate_logpolar: gaze centre out of range");
+  if (is->iw != source_width || is->ih != source_height || !is->irad_dev.p) {
+    F360_HIP_TRY(hipSetDevice(is->ctx->device));
+    std::vector<float> rad;
+    std::vector<double> cs, sn;
+    f360::build_logpolar_inverse_axes(rad, cs, sn, source_width, source_height);
+    int st = upload(is->ctx, is->irad_dev, rad.data(), rad.size() * sizeof(float));
+    if (st != F360_OK) return st;
+    st = upload(is->ctx, is->icos_dev, cs.data(), cs.size() * sizeof(double));
+    if (st != F360_OK) return st;
+    st = upload(is->ctx, is->isin_dev, sn.data(), sn.size() * sizeof(double));
+    if (st != F360_OK) return st;
+    is->iw = source_width;
+    is->ih = source_height;
+  }
+  const float cxf = center_x * (float)target_width;
+  const float cyf = center_y * (float)target_height;
+  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  hipLaunchKernelGGL(is_interpolate_logpolar_kernel, grid, dim3(256), 0,
+                     is->ctx->stream, reinterpret_cast<uint32_t *>(target_dev),
+                     target_width, target_height,
+                     reinterpret_cast<const uint32_t *>(source_dev), source_width,
+                     source_height, is->irad_dev.as<float>(),
+                     is->icos_dev.as<double>(), is->isin_dev.as<double>(), cxf, cyf,
+                     (int)cxf, (int)cyf);
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+int f360_is_logpolar_gaussian_blur(f360_image_sampler *is, uint8_t *target_dev,
+                                   int target_width, int target_height,
+                                   int target_linesize,
+                                   const uint8_t *source_dev) {
+  (void)target_linesize;  // kernel indexes 4-byte texels with a row stride of width
+  F360_REQUIRE(is, "f360_is_logpolar_gaussian_blur: null sampler");
+  F360_REQUIRE(target_dev && source_dev, "f360_is_logpolar_gaussian_blur: null buffer");
+  F360_REQUIRE(target_width >= 1 && target_height >= 1,
+               "f360_is_logpolar_gaussian_blur: bad geometry");
+  F360_REQUIRE(((uintptr_t)target_dev % 4) == 0 && ((uintptr_t)source_dev % 4) == 0,
+               "f360_is_logpolar_gaussian_blur: buffers must be 4-byte aligned");
+  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  hipLaunchKernelGGL(is_blur_kernel, grid, dim3(256), 0, is->ctx->stream,
+                     reinterpret_cast<uint32_t *>(target_dev), target_width,
+                     target_height, reinterpret_cast<const uint32_t *>(source_dev));
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// projections.hip -- equirectangular -> rectilinear (inverse gnomonic) remap.
+//
+// Replaces Projections::GnomonicProjection (src/projections.cc:51-86) and
+// gnomonic_kernel (src/projections_program.cl:7-47).  Float builtins are
+// evaluated as correctly rounded floats (DESIGN.md "Float model"); the two
+// gaze-only angles and their sin/cos are computed once on the host.
+#include <cmath>
+
+#include "f360_internal.h"
+
+namespace {
+
+#define F360_PI 3.141592653589793
+#define F360_PI_2 1.5707963267948966
+
+__device__ __forceinline__ float cr_atanf(float x) { return (float)atan((double)x); }
+__device__ __forceinline__ float cr_sinf(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cr_cosf(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float cr_asinf(float x) { return (float)asin((double)x); }
+__device__ __forceinline__ float cr_atan2f(float y, float x) {
+  return (float)atan2((double)y, (double)x);
+}
+
+__global__ __launch_bounds__(256) void gnomonic_kernel(
+    uint32_t *__restrict__ dst, int dst_w, int dst_h,
+    const uint32_t *__restrict__ src, int src_w, int src_h, float lambda0,
+    float sp1, float cp1) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= dst_w || j >= dst_h) return;
+  const float x = 6.0f * ((float)i / (float)dst_w - 0.5f);  // scale = (6, 3)
+  const float y = 3.0f * ((float)j / (float)dst_h - 0.5f);
+  const float rho = sqrtf(x * x + y * y);
+  const float c = cr_atanf(rho);
+  const float sc = cr_sinf(c), cc = cr_cosf(c);
+  float phi = cr_asinf(cc * sp1 + (y * sc * cp1) / rho);
+  float lam = lambda0 + cr_atan2f(x * sc, rho * cp1 * cc - y * sp1 * sc);
+  phi = (float)fmod((double)phi + F360_PI_2 + 10 * F360_PI, 2 * F360_PI);
+  lam = (float)fmod((double)lam + F360_PI + 10 * F360_PI, 2 * F360_PI);
+  float su = (float)((double)lam / (2.0 * F360_PI));
+  float sv = (float)((double)phi / (F360_PI));
+  // clamp() = fmin(fmax(x, lo), hi): the NaN of the exact viewport centre
+  // (rho == 0 -> 0/0) clamps to 0
+  su = fminf(fmaxf(su, 0.0f), 0.999f);
+  sv = fminf(fmaxf(sv, 0.0f), 0.999f);
+  const size_t texel =
+      (size_t)(int)(sv * (float)src_h) * src_w + (int)(su * (float)src_w);
+  dst[(size_t)j * dst_w + i] = src[texel] & 0x00ffffffu;
+}
+
+}  // namespace
+
+extern "C" int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_width,
+                             int target_height, int target_linesize,
+                             const uint8_t *source_dev, int source_width,
+                             int source_height, int source_linesize,
+                             float center_x, float center_y) {
+  (void)target_linesize;  // 4-byte texels, tightly packed rows, as in the kernel
+  (void)source_linesize;
+  F360_REQUIRE(ctx, "f360_gnomonic: null context");
+  F360_REQUIRE(target_dev && source_dev, "f360_gnomonic: null buffer");
+  F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 1 &&
+                   source_height >= 1,
+               "f360_gnomonic: bad geometry");
+  F360_REQUIRE(((uintptr_t)target_dev % 4) == 0 && ((uintptr_t)source_dev % 4) == 0,
+               "f360_gnomonic: buffers must be 4-byte aligned");
+  F360_REQUIRE(std::fabs(center_x) <= 16.0f && std::fabs(center_y) <= 16.0f,
+               "f360_gnomonic: gaze centre out of range");
+  // float phi1 = (center.y - 0.5) * PI; float lambda0 = (center.x - 0.5) * 2.0 * PI;
+  const float phi1 = (float)(((double)center_y - 0.5) * F360_PI);
+  const float lambda0 = (float)(((double)center_x - 0.5) * 2.0 * F360_PI);
+  const float sp1 = (float)std::sin((double)phi1);
+  const float cp1 = (float)std::cos((double)phi1);
+  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  hipLaunchKernelGGL(gnomonic_kernel, grid, dim3(256), 0, ctx->stream,
+                     reinterpret_cast<uint32_t *>(target_dev), target_width,
+                     target_height, reinterpret_cast<const uint32_t *>(source_dev),
+                     source_width, source_height, lambda0, sp1, cp1);
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}

@@ -1,0 +1,453 @@
+// sat_encode.hip -- summed-area-table encode for gfx950 (MI355X).
+//
+// Replaces SATEncoder::EncodeFrameGPU (src/sat_encoder.cc:67-135) and its three
+// OpenCL kernels copy_image / scan_rows / scan_columns
+// (src/sat_encoder_encode_kernels.cl:1-20,44-58,60-74).  Output is bit-identical:
+// uint32 addition is associative mod 2^32, so any summation order gives the
+// reference's integers.
+//
+// Design (DESIGN.md "SAT encode"): reduce -> carry scan -> write.
+//   A wave owns a strip of 256 pixels (64 lanes x 4 RGB0 pixels = one 16-byte
+//   load per lane and row).  The frame is cut into bands of `band_rows` rows
+//   and super-bands of `sb_bands` bands.
+//   K1 sat_reduce : one wave per (strip, super-band) walks down the super-band
+//                   and emits the column sums above each band (inside the
+//                   super-band), the super-band column sums, every row's
+//                   strip sum and every tile's sum.        reads 4 B/px
+//   K2 sat_carry  : exclusive prefixes of those small arrays across
+//                   super-bands / across strips.           ~1 % of the traffic
+//   K3 sat_write  : one wave per (strip, band) re-reads its pixels, rebuilds
+//                   the row prefix with a DPP wave scan, adds the carried-in
+//                   column / row / corner sums and writes the final uint32x3
+//                   table once.                     reads 4 B/px, writes 12 B/px
+//   Total HBM traffic ~20.6 B/px against 16 B/px compulsory (the reference's
+//   three passes move 64 B/px).
+#include "f360_internal.h"
+
+namespace {
+
+constexpr int kLanePx = 4;                 // pixels per lane
+constexpr int kStripPx = 64 * kLanePx;     // pixels per wave-row
+constexpr int kWavesPerBlock = 4;
+constexpr int kRowUnroll = 8;              // rows whose loads are issued together
+
+// ---- wave64 DPP helpers ---------------------------------------------------
+// dpp_ctrl: 0x110+n row_shr:n, 0x142 row_bcast:15, 0x143 row_bcast:31.
+#define F360_DPP_ADD(v, ctrl, row_mask)                                        \
+  (v) += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (row_mask), \
+                                               0xf, false)
+
+// Inclusive prefix sum over the 64 lanes of a wave (mod 2^32).
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+  F360_DPP_ADD(v, 0x111, 0xf);  // within each row of 16 lanes: Kogge-Stone
+  F360_DPP_ADD(v, 0x112, 0xf);
+  F360_DPP_ADD(v, 0x114, 0xf);
+  F360_DPP_ADD(v, 0x118, 0xf);
+  F360_DPP_ADD(v, 0x142, 0xa);  // rows 1,3 += last lane of rows 0,2
+  F360_DPP_ADD(v, 0x143, 0xc);  // rows 2,3 += lane 31
+  return v;
+}
+
+struct EncodeArgs {
+  uint32_t *sat;
+  const uint8_t *src;
+  int width, height, linesize, bpp;
+  int band_rows, sb_bands, nstrips, nbands, nsb, wp3;
+  uint32_t *lp, *sbtotal, *sbprefix, *rowsum, *rowcarry, *tiletotal, *tprefix;
+  int reverse;
+};
+
+// Four pixels of one row as packed R | G<<8 | B<<16 dwords (0 beyond the row).
+template <bool VEC>
+__device__ __forceinline__ uint4 load_px4(const uint8_t *src, int width, int y,
+                                          int x0, int linesize, int bpp) {
+  if (VEC) {
+    if (x0 < width)
+      return *reinterpret_cast<const uint4 *>(src + (size_t)y * linesize +
+                                              (size_t)x0 * 4);
+    return make_uint4(0, 0, 0, 0);
+  }
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = 0;
+    if (x0 + k < width) {
+      const uint8_t *p = src + (size_t)y * linesize + (size_t)(x0 + k) * bpp;
+      v[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+  }
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+__device__ __forceinline__ void unpack_px4(const uint4 &raw, uint32_t (&c)[12]) {
+  const uint32_t v[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c[3 * k + 0] = v[k] & 0xffu;
+    c[3 * k + 1] = (v[k] >> 8) & 0xffu;
+    c[3 * k + 2] = (v[k] >> 16) & 0xffu;
+  }
+}
+
+__device__ __forceinline__ void store12(uint32_t *dst, const uint32_t (&a)[12]) {
+  uint4 *d = reinterpret_cast<uint4 *>(dst);
+  d[0] = make_uint4(a[0], a[1], a[2], a[3]);
+  d[1] = make_uint4(a[4], a[5], a[6], a[7]);
+  d[2] = make_uint4(a[8], a[9], a[10], a[11]);
+}
+
+__device__ __forceinline__ void load12(const uint32_t *src, uint32_t (&a)[12]) {
+  const uint4 *s = reinterpret_cast<const uint4 *>(src);
+  const uint4 q0 = s[0], q1 = s[1], q2 = s[2];
+  a[0] = q0.x; a[1] = q0.y; a[2] = q0.z; a[3] = q0.w;
+  a[4] = q1.x; a[5] = q1.y; a[6] = q1.z; a[7] = q1.w;
+  a[8] = q2.x; a[9] = q2.y; a[10] = q2.z; a[11] = q2.w;
+}
+
+// ---- K1: column / row / tile sums ------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
+    const EncodeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int strip = __builtin_amdgcn_readfirstlane(
+      (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
+  const int sb = blockIdx.y;
+  if (strip >= a.nstrips) return;
+  const int x0 = strip * kStripPx + lane * kLanePx;
+
+  uint32_t col[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) col[e] = 0;
+
+  const int band_end = min((sb + 1) * a.sb_bands, a.nbands);
+  for (int band = sb * a.sb_bands; band < band_end; ++band) {
+    store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, col);
+    const int y_end = min((band + 1) * a.band_rows, a.height);
+    uint32_t tile_rg = 0, tile_b = 0, tile_g_hi = 0;  // lane 63 only
+    for (int y = band * a.band_rows; y < y_end; y += kRowUnroll) {
+      uint4 raw[kRowUnroll];
+#pragma unroll
+      for (int r = 0; r < kRowUnroll; ++r)
+        raw[r] = (y + r < y_end)
+                     ? load_px4<VEC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
+                     : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < kRowUnroll; ++r) {
+        if (y + r >= y_end) break;
+        uint32_t c[12];
+        unpack_px4(raw[r], c);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) col[e] += c[e];
+        // strip sum of this row: R and G share one scan (each < 2^16)
+        const uint32_t sr = c[0] + c[3] + c[6] + c[9];
+        const uint32_t sg = c[1] + c[4] + c[7] + c[10];
+        const uint32_t sbl = c[2] + c[5] + c[8] + c[11];
+        const uint32_t inc_rg = wave_scan_incl(sr | (sg << 16));
+        const uint32_t inc_b = wave_scan_incl(sbl);
+        if (lane == 63) {
+          uint32_t *rs = a.rowsum + ((size_t)strip * a.height + (y + r)) * 3;
+          rs[0] = inc_rg & 0xffffu;
+          rs[1] = inc_rg >> 16;
+          rs[2] = inc_b;
+          tile_rg += inc_rg & 0xffffu;
+          tile_g_hi += inc_rg >> 16;
+          tile_b += inc_b;
+        }
+      }
+    }
+    if (lane == 63) {
+      uint32_t *tt = a.tiletotal + ((size_t)strip * a.nbands + band) * 3;
+      tt[0] = tile_rg;
+      tt[1] = tile_g_hi;
+      tt[2] = tile_b;
+    }
+  }
+  store12(a.sbtotal + (size_t)sb * a.wp3 + (size_t)x0 * 3, col);
+}
+
+// ---- K2: exclusive prefixes of the carry arrays ------------------------------
+// out[k][i] = sum_{k' < k} in[k'][i]   for i < n, k < K
+struct ScanSeg {
+  const uint32_t *in;
+  uint32_t *out;
+  int n, K, nblocks;
+};
+
+__device__ __forceinline__ void carry_scan_segment(const ScanSeg &s, int blk) {
+  const int i = blk * 256 + (int)threadIdx.x;
+  if (i >= s.n) return;
+  uint32_t run = 0;
+  int k = 0;
+  for (; k + 8 <= s.K; k += 8) {
+    uint32_t t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = s.in[(size_t)(k + q) * s.n + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      s.out[(size_t)(k + q) * s.n + i] = run;
+      run += t[q];
+    }
+  }
+  for (; k < s.K; ++k) {
+    const uint32_t t = s.in[(size_t)k * s.n + i];
+    s.out[(size_t)k * s.n + i] = run;
+    run += t;
+  }
+}
+
+__global__ __launch_bounds__(256) void sat_carry_kernel(const ScanSeg a,
+                                                        const ScanSeg b,
+                                                        const ScanSeg c) {
+  int blk = blockIdx.x;
+  if (blk < a.nblocks) {
+    carry_scan_segment(a, blk);
+    return;
+  }
+  blk -= a.nblocks;
+  if (blk < b.nblocks) {
+    carry_scan_segment(b, blk);
+    return;
+  }
+  blk -= b.nblocks;
+  carry_scan_segment(c, blk);
+}
+
+// ---- K3: final table ----------------------------------------------------------
+// STORE 0: three 16-byte stores per lane at a 48-byte lane stride.
+// STORE 1: re-stage the row through wave-private LDS so that each store
+//          instruction writes 1 KiB contiguous.
+template <bool VEC, int STORE>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
+    const EncodeArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t
+      stage[STORE == 1 ? kWavesPerBlock * 3 * kStripPx : 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int bx = blockIdx.x, band = blockIdx.y;
+  if (a.reverse) {
+    bx = (int)gridDim.x - 1 - bx;
+    band = (int)gridDim.y - 1 - band;
+  }
+  const int strip =
+      __builtin_amdgcn_readfirstlane(bx * kWavesPerBlock + wave);
+  if (strip >= a.nstrips) return;
+  const int x0 = strip * kStripPx + lane * kLanePx;
+  const int sb = band / a.sb_bands;
+
+  // --- table row just above the band, for this lane's 4 pixels -------------
+  uint32_t acc[12];
+  {
+    uint32_t t0[12], t1[12];
+    load12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, t0);
+    load12(a.sbprefix + (size_t)sb * a.wp3 + (size_t)x0 * 3, t1);
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = t0[e] + t1[e];
+  }
+  // corner: every tile above and to the left
+  uint32_t corner[3] = {0, 0, 0};
+  for (int b = lane; b < band; b += 64) {
+    const uint32_t *tp = a.tprefix + ((size_t)strip * a.nbands + b) * 3;
+    corner[0] += tp[0];
+    corner[1] += tp[1];
+    corner[2] += tp[2];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    corner[c] = (uint32_t)__builtin_amdgcn_readlane(
+        (int)wave_scan_incl(corner[c]), 63);
+    // prefix along x of the column sums: inside the lane, then across lanes
+    acc[3 + c] += acc[c];
+    acc[6 + c] += acc[3 + c];
+    acc[9 + c] += acc[6 + c];
+    const uint32_t excl = wave_scan_incl(acc[9 + c]) - acc[9 + c] + corner[c];
+    acc[c] += excl;
+    acc[3 + c] += excl;
+    acc[6 + c] += excl;
+    acc[9 + c] += excl;
+  }
+
+  const int y_end = min((band + 1) * a.band_rows, a.height);
+  const uint32_t *rc = a.rowcarry + (size_t)strip * a.height * 3;
+  for (int y = band * a.band_rows; y < y_end; y += kRowUnroll) {
+    uint4 raw[kRowUnroll];
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r)
+      raw[r] = (y + r < y_end)
+                   ? load_px4<VEC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
+                   : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r) {
+      if (y + r >= y_end) break;
+      uint32_t c[12];
+      unpack_px4(raw[r], c);
+      // inclusive prefix over the lane's 4 pixels
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        c[3 * k + 0] += c[3 * k - 3];
+        c[3 * k + 1] += c[3 * k - 2];
+        c[3 * k + 2] += c[3 * k - 1];
+      }
+      const uint32_t inc_rg = wave_scan_incl(c[9] | (c[10] << 16));
+      const uint32_t inc_b = wave_scan_incl(c[11]);
+      const uint32_t base_r = (inc_rg & 0xffffu) - c[9] + rc[(size_t)(y + r) * 3 + 0];
+      const uint32_t base_g = (inc_rg >> 16) - c[10] + rc[(size_t)(y + r) * 3 + 1];
+      const uint32_t base_b = inc_b - c[11] + rc[(size_t)(y + r) * 3 + 2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[3 * k + 0] += c[3 * k + 0] + base_r;
+        acc[3 * k + 1] += c[3 * k + 1] + base_g;
+        acc[3 * k + 2] += c[3 * k + 2] + base_b;
+      }
+      uint32_t *row = a.sat + (size_t)(y + r) * a.width * 3;
+      if (VEC && STORE == 0) {
+        if (x0 < a.width) store12(row + (size_t)x0 * 3, acc);
+      } else if (VEC && STORE == 1) {
+        uint32_t *mine = stage + wave * 3 * kStripPx;
+        store12(mine + lane * 12, acc);
+        const int row_dwords = a.width * 3;
+        const int base = strip * kStripPx * 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int off = q * 256 + lane * 4;
+          const uint4 v = *reinterpret_cast<const uint4 *>(mine + off);
+          if (base + off < row_dwords)  // width % 4 == 0 -> whole 16 B in range
+            *reinterpret_cast<uint4 *>(row + base + off) = v;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (x0 + k < a.width) {
+            row[(size_t)(x0 + k) * 3 + 0] = acc[3 * k + 0];
+            row[(size_t)(x0 + k) * 3 + 1] = acc[3 * k + 1];
+            row[(size_t)(x0 + k) * 3 + 2] = acc[3 * k + 2];
+          }
+      }
+    }
+  }
+}
+
+int ensure_plan(f360_ctx *ctx, int width, int height) {
+  f360::SatEncodePlan &p = ctx->enc;
+  if (p.width == width && p.height == height &&
+      p.band_rows == ctx->opt_band_rows && p.sb_bands == ctx->opt_sb_bands &&
+      p.ws.p)
+    return F360_OK;
+  // A geometry change re-carves the scratch; wait for work that may use it.
+  if (p.ws.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  p.width = width;
+  p.height = height;
+  p.band_rows = ctx->opt_band_rows;
+  p.sb_bands = ctx->opt_sb_bands;
+  p.nstrips = (width + kStripPx - 1) / kStripPx;
+  p.nbands = (height + p.band_rows - 1) / p.band_rows;
+  p.nsb = (p.nbands + p.sb_bands - 1) / p.sb_bands;
+  p.wp3 = p.nstrips * kStripPx * 3;
+  auto align = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  const size_t n_lp = align((size_t)p.nbands * p.wp3);
+  const size_t n_sb = align((size_t)p.nsb * p.wp3);
+  const size_t n_row = align((size_t)p.nstrips * height * 3);
+  const size_t n_tile = align((size_t)p.nstrips * p.nbands * 3);
+  const size_t total = n_lp + 2 * n_sb + 2 * n_row + 2 * n_tile;
+  int st = p.ws.reserve(total * sizeof(uint32_t));
+  if (st != F360_OK) {
+    p.width = p.height = 0;
+    return st;
+  }
+  uint32_t *w = p.ws.as<uint32_t>();
+  p.lp = w;             w += n_lp;
+  p.sbtotal = w;        w += n_sb;
+  p.sbprefix = w;       w += n_sb;
+  p.rowsum = w;         w += n_row;
+  p.rowcarry = w;       w += n_row;
+  p.tiletotal = w;      w += n_tile;
+  p.tprefix = w;
+  return F360_OK;
+}
+
+}  // namespace
+
+extern "C" int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height) {
+  F360_REQUIRE(ctx, "f360_sat_encode_prepare: null context");
+  F360_REQUIRE(width >= 1 && height >= 1, "f360_sat_encode_prepare: bad size %dx%d",
+               width, height);
+  F360_HIP_TRY(hipSetDevice(ctx->device));
+  return ensure_plan(ctx, width, height);
+}
+
+extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
+                               const uint8_t *src_dev, int width, int height,
+                               int linesize) {
+  F360_REQUIRE(ctx, "f360_sat_encode: null context");
+  F360_REQUIRE(sat_dev && src_dev, "f360_sat_encode: null buffer");
+  F360_REQUIRE(width >= 1 && height >= 1, "f360_sat_encode: bad size %dx%d", width,
+               height);
+  const int bpp = linesize / width;  // src/sat_encoder_encode_kernels.cl:9
+  F360_REQUIRE(bpp >= 3, "f360_sat_encode: linesize %d gives %d bytes per pixel (need >= 3)",
+               linesize, bpp);
+  F360_REQUIRE((size_t)width * height * 3 < ((size_t)1 << 31),
+               "f360_sat_encode: frame too large for 32-bit element indices");
+  int st = ensure_plan(ctx, width, height);
+  if (st != F360_OK) return st;
+  const f360::SatEncodePlan &p = ctx->enc;
+
+  EncodeArgs a;
+  a.sat = sat_dev;
+  a.src = src_dev;
+  a.width = width;
+  a.height = height;
+  a.linesize = linesize;
+  a.bpp = bpp;
+  a.band_rows = p.band_rows;
+  a.sb_bands = p.sb_bands;
+  a.nstrips = p.nstrips;
+  a.nbands = p.nbands;
+  a.nsb = p.nsb;
+  a.wp3 = p.wp3;
+  a.lp = p.lp;
+  a.sbtotal = p.sbtotal;
+  a.sbprefix = p.sbprefix;
+  a.rowsum = p.rowsum;
+  a.rowcarry = p.rowcarry;
+  a.tiletotal = p.tiletotal;
+  a.tprefix = p.tprefix;
+  a.reverse = ctx->opt_reverse_tiles;
+
+  const bool prof = f360::take_profile_slot(ctx);
+  const bool vec = bpp == 4 && (width % 4) == 0 && (linesize % 16) == 0 &&
+                   ((uintptr_t)src_dev % 16) == 0 && ((uintptr_t)sat_dev % 16) == 0;
+  const dim3 block(64 * kWavesPerBlock);
+  const int bx = (p.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
+
+  {
+    f360::KernelSpan span(ctx, f360::kSatReduce, prof);
+    if (vec)
+      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(bx, p.nsb), block, 0,
+                         ctx->stream, a);
+    else
+      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(bx, p.nsb), block, 0,
+                         ctx->stream, a);
+  }
+
+  ScanSeg sa{p.sbtotal, p.sbprefix, p.wp3, p.nsb, (p.wp3 + 255) / 256};
+  ScanSeg sb{p.rowsum, p.rowcarry, height * 3, p.nstrips, (height * 3 + 255) / 256};
+  ScanSeg sc{p.tiletotal, p.tprefix, p.nbands * 3, p.nstrips,
+             (p.nbands * 3 + 255) / 256};
+  {
+    f360::KernelSpan span(ctx, f360::kSatCarry, prof);
+    hipLaunchKernelGGL(sat_carry_kernel,
+                       dim3(sa.nblocks + sb.nblocks + sc.nblocks), dim3(256), 0,
+                       ctx->stream, sa, sb, sc);
+  }
+  {
+    f360::KernelSpan span(ctx, f360::kSatWrite, prof);
+    const dim3 grid3(bx, p.nbands);
+    if (!vec)
+      hipLaunchKernelGGL((sat_write_kernel<false, 0>), grid3, block, 0, ctx->stream, a);
+    else if (ctx->opt_store_mode == 1)
+      hipLaunchKernelGGL((sat_write_kernel<true, 1>), grid3, block, 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL((sat_write_kernel<true, 0>), grid3, block, 0, ctx->stream, a);
+  }
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}

@@ -1,0 +1,253 @@
+/*
+ * f360.h -- C ABI of the MI355X-native foveated-360 frame-transform engine.
+ *
+ * This is the drop-in boundary.  It replaces the reference's OpenCLManager +
+ * cl_kernel plumbing (src/opencl_manager.{h,cc}) underneath the reference's
+ * SATEncoder / SATDecoder / ImageSampler / Projections classes; the C++
+ * mirrors of those classes live in the include/f360/ directory and are thin inline
+ * wrappers over the functions below.  Plain pointers and sizes only: a
+ * "device pointer" is whatever hipMalloc / f360_malloc returned (or
+ * torch.Tensor.data_ptr()).
+ *
+ * Execution model (mirrors the reference): every transform only
+ * ENQUEUES work on the context's single in-order HIP stream and returns;
+ * ordering between encode -> sample -> interpolate relies on that stream; the
+ * caller forces completion with f360_sync() or a blocking f360_memcpy_*.
+ * Objects are not thread-safe; use one context (+ decoder/sampler) per thread,
+ * exactly like one OpenCLManager per connection thread in the reference.
+ *
+ * All functions return F360_OK (0) or a negative f360_status; the message of
+ * the last failure on the calling thread is available from
+ * f360_last_error_string().  There is NO CPU fallback: without a HIP device
+ * every entry point that touches the device fails with F360_ERR_NO_DEVICE.
+ */
+#ifndef F360_H
+#define F360_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F360_VERSION_MAJOR 0
+#define F360_VERSION_MINOR 1
+
+typedef enum f360_status {
+  F360_OK = 0,
+  F360_ERR_INVALID_ARG = -1,
+  F360_ERR_NO_DEVICE = -2,
+  F360_ERR_HIP = -3,
+  F360_ERR_OOM = -4,
+  F360_ERR_NOT_INITIALIZED = -5
+} f360_status;
+
+typedef struct f360_ctx f360_ctx;                     /* replaces OpenCLManager */
+typedef struct f360_sat_decoder f360_sat_decoder;     /* state of SATDecoder    */
+typedef struct f360_image_sampler f360_image_sampler; /* state of ImageSampler  */
+
+/* ---- runtime: replaces OpenCLManager (src/opencl_manager.h:8-22,
+ *      src/opencl_manager.cc:7-67: platform/device/context/in-order queue) -- */
+int f360_version(void);
+const char *f360_last_error_string(void);
+const char *f360_status_string(int status); /* OpenCLManager::GetCLErrorString */
+int f360_device_count(int *count);
+/* OpenCLManager::InitializeContext(): device `device`, one new in-order
+ * stream owned by the context. */
+int f360_ctx_create(int device, f360_ctx **out);
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch's current
+ * stream); the stream is borrowed, not destroyed. */
+int f360_ctx_create_on_stream(int device, void *hip_stream, f360_ctx **out);
+int f360_ctx_destroy(f360_ctx *ctx);
+int f360_ctx_device(const f360_ctx *ctx, int *device);
+int f360_ctx_stream(const f360_ctx *ctx, void **hip_stream);
+/* clFlush + clFinish (src/video_server.cc:302-303) */
+int f360_sync(f360_ctx *ctx);
+
+/* ---- buffers: replaces cl::Buffer / cl::copy
+ *      (src/video_server.cc:224-232,298-299,342-345) -------------------------- */
+int f360_malloc(f360_ctx *ctx, size_t bytes, void **dptr);
+int f360_free(f360_ctx *ctx, void *dptr);
+int f360_memset(f360_ctx *ctx, void *dptr, int value, size_t bytes); /* async */
+/* blocking copies (cl::copy semantics: returns when the copy is done) */
+int f360_memcpy_h2d(f360_ctx *ctx, void *dst_dev, const void *src_host,
+                    size_t bytes);
+int f360_memcpy_d2h(f360_ctx *ctx, void *dst_host, const void *src_dev,
+                    size_t bytes);
+/* stream-ordered copies (host memory should be pinned for true asynchrony) */
+int f360_memcpy_h2d_async(f360_ctx *ctx, void *dst_dev, const void *src_host,
+                          size_t bytes);
+int f360_memcpy_d2h_async(f360_ctx *ctx, void *dst_host, const void *src_dev,
+                          size_t bytes);
+int f360_host_alloc_pinned(size_t bytes, void **hptr);
+int f360_host_free_pinned(void *hptr);
+
+/* ---- timing helpers (HIP events on the context's stream; used by bench.py
+ *      to time kernels on the stream they are launched on) ------------------ */
+typedef struct f360_event f360_event;
+int f360_event_create(f360_ctx *ctx, f360_event **ev);
+int f360_event_destroy(f360_event *ev);
+int f360_event_record(f360_ctx *ctx, f360_event *ev);
+int f360_event_elapsed_ms(f360_event *start, f360_event *stop, float *ms);
+
+/* ---- SATEncoder --------------------------------------------------------- */
+/* SATEncoder::EncodeFrameGPU (src/sat_encoder.h:39-40, src/sat_encoder.cc
+ * :67-135; kernels src/sat_encoder_encode_kernels.cl:1-20,44-74).
+ *   sat_dev : uint32[height][width][3] (row stride 3*width elements)
+ *   src_dev : packed 8-bit frame, `linesize` bytes per row,
+ *             bytes-per-pixel = linesize / width (4 for RGB0, 3 for RGB24)
+ * Any width/height >= 1 is accepted (the reference needs multiples of 8). */
+int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev,
+                    int width, int height, int linesize);
+/* Optional: allocate the encoder's scratch for a geometry ahead of time so
+ * that f360_sat_encode itself never allocates (graph-capture safe). */
+int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height);
+
+/* ---- SATDecoder --------------------------------------------------------- */
+int f360_satdec_create(f360_ctx *ctx, f360_sat_decoder **out);
+int f360_satdec_destroy(f360_sat_decoder *dec);
+/* SATDecoder::InitializeGrid (src/sat_decoder.h:48-49, src/sat_decoder.cc
+ * :139-174; create_grid_kernel src/sat_decoder_sample_rect_kernel.cl:243-295).
+ * No-op when the geometry is unchanged. */
+int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
+                                int target_height, int source_width,
+                                int source_height);
+/* Export the grid in the reference's layout short[(Hr+1)][(Wr+1)][2] (host
+ * buffer) -- for parity checks against create_grid_kernel. */
+int f360_satdec_export_grid(f360_sat_decoder *dec, int16_t *grid_host);
+/* SATDecoder::SampleFrameRectGPU (src/sat_decoder.h:63-66, src/sat_decoder.cc
+ * :301-348; sample_rect_kernel src/sat_decoder_sample_rect_kernel.cl:138-241).
+ * Writes bytes 0..2 of each 4-byte target pixel; byte 3 and pixels whose box
+ * falls outside the frame are left untouched, as in the reference.
+ * Initialises the grid on first use (src/sat_decoder.cc:312-317). */
+int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
+                            int target_width, int target_height,
+                            int target_linesize, const uint32_t *sat_dev,
+                            int source_width, int source_height, float center_x,
+                            float center_y);
+/* SATDecoder::InterpolateFrameRectGPU (src/sat_decoder.h:77-82,
+ * src/sat_decoder.cc:887-928; interpolate_rect_kernel
+ * src/sat_decoder_interpolate_kernel.cl:1-152).  Like the reference kernel the
+ * buffers are 4-byte texels with tightly packed rows; the two linesize
+ * arguments are accepted and ignored (src/sat_decoder.cc:902-912 never passes
+ * them).  The pad byte of every target texel is written as 0. */
+int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
+                                 int target_width, int target_height,
+                                 int target_linesize, const uint8_t *source_dev,
+                                 int source_width, int source_height,
+                                 int source_linesize, float center_x,
+                                 float center_y);
+/* SATDecoder::DecodeFrameGPU (src/sat_decoder.h:50-51, src/sat_decoder.cc
+ * :176-210; decode_kernel src/sat_decoder_decode_kernel.cl:1-58).  The
+ * reference launch uses work_dim 0 and always fails; this one runs. */
+int f360_satdec_decode(f360_sat_decoder *dec, uint8_t *target_dev,
+                       int target_linesize, const uint32_t *sat_dev, int width,
+                       int height);
+
+/* ---- ImageSampler ------------------------------------------------------- */
+int f360_is_create(f360_ctx *ctx, f360_image_sampler **out);
+int f360_is_destroy(f360_image_sampler *is);
+/* ImageSampler::InitializeGrid (src/image_sampler.h:57-58,
+ * src/image_sampler.cc:170-201; create_grid_kernel
+ * src/image_sampler_sample_rect_kernel.cl:48-88) */
+int f360_is_initialize_grid(f360_image_sampler *is, int target_width,
+                            int target_height, int source_width,
+                            int source_height);
+/* ImageSampler::InitializeLogpolarGrid (src/image_sampler.h:59-60,
+ * src/image_sampler.cc:203-245; create_logpolar_grid_kernel
+ * src/image_sampler_sample_logpolar_kernel.cl:5-39) */
+int f360_is_initialize_logpolar_grid(f360_image_sampler *is, int target_width,
+                                     int target_height, int source_width,
+                                     int source_height);
+/* reference layouts short[Hr][Wr][2] (host buffers), for parity checks */
+int f360_is_export_grid(f360_image_sampler *is, int16_t *grid_host);
+int f360_is_export_logpolar_grid(f360_image_sampler *is, int16_t *grid_host);
+/* ImageSampler::SampleFrameRectGPU (src/image_sampler.h:61-65,
+ * src/image_sampler.cc:247-299; sample_rect_kernel
+ * src/image_sampler_sample_rect_kernel.cl:1-46).  Requires InitializeGrid
+ * (the reference's auto-init test `grid_size == -1` never fires,
+ * src/image_sampler.cc:261). */
+int f360_is_sample_rect(f360_image_sampler *is, uint8_t *target_dev,
+                        int target_width, int target_height,
+                        int target_linesize, const uint8_t *source_dev,
+                        int source_width, int source_height,
+                        int source_linesize, float center_x, float center_y);
+/* ImageSampler::SampleFrameLogPolarGPU (src/image_sampler.h:75-79,
+ * src/image_sampler.cc:577-621; sample_logpolar_kernel
+ * src/image_sampler_sample_logpolar_kernel.cl:41-86) */
+int f360_is_sample_logpolar(f360_image_sampler *is, uint8_t *target_dev,
+                            int target_width, int target_height,
+                            int target_linesize, const uint8_t *source_dev,
+                            int source_width, int source_height,
+                            int source_linesize, float center_x,
+                            float center_y);
+/* ImageSampler::InterpolateFrameLogPolarGPU (src/image_sampler.h:85-89,
+ * src/image_sampler.cc:780-819; interpolate_logpolar_kernel
+ * src/image_sampler_interpolate_kernel.cl:1-81).  4-byte texels, tight rows,
+ * linesizes ignored like the reference; pad byte written as 0. */
+int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
+                                 int target_width, int target_height,
+                                 int target_linesize, const uint8_t *source_dev,
+                                 int source_width, int source_height,
+                                 int source_linesize, float center_x,
+                                 float center_y);
+/* ImageSampler::ApplyLogPolarGaussianBlur (src/image_sampler.h:90-92,
+ * src/image_sampler.cc:821-857; logpolar_gaussian_blur_kernel
+ * src/image_sampler_sample_logpolar_kernel.cl:88-142) */
+int f360_is_logpolar_gaussian_blur(f360_image_sampler *is, uint8_t *target_dev,
+                                   int target_width, int target_height,
+                                   int target_linesize,
+                                   const uint8_t *source_dev);
+
+/* ---- Projections -------------------------------------------------------- */
+/* Projections::GnomonicProjection (src/projections.h:31-35,
+ * src/projections.cc:51-86; gnomonic_kernel src/projections_program.cl:7-47).
+ * Argument ORDER follows the .cc definition (width, then height). */
+int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_width,
+                  int target_height, int target_linesize,
+                  const uint8_t *source_dev, int source_width,
+                  int source_height, int source_linesize, float center_x,
+                  float center_y);
+
+/* ---- host-only geometry tables (no device needed) -------------------------
+ * The 1-D factors the kernels read instead of the reference's 2-D grids and
+ * per-pixel transcendentals; exported so the host logic can be checked on a
+ * machine without a GPU. */
+/* n_out+1 midpoint offsets of create_grid_kernel
+ * (src/sat_decoder_sample_rect_kernel.cl:243-295), one axis */
+int f360_tables_satdec_grid_axis(int16_t *out, int n_out, int n_src);
+/* n_out offsets of ImageSampler's create_grid_kernel
+ * (src/image_sampler_sample_rect_kernel.cl:48-88), one axis */
+int f360_tables_is_grid_axis(int16_t *out, int n_out, int n_src);
+/* radius[out_w], cos[out_h], sin[out_h] (float) of create_logpolar_grid_kernel
+ * (src/image_sampler_sample_logpolar_kernel.cl:5-39) */
+int f360_tables_logpolar_axes(float *radius, float *cs, float *sn, int out_w,
+                              int out_h);
+/* (2*range+1) x {u, dcalc, dmin, du} (int32) of interpolate_rect_kernel
+ * (src/sat_decoder_interpolate_kernel.cl:43-89), one axis, indexed by the
+ * pixel offset from the gaze centre + range */
+int f360_tables_interp_axis(int32_t *out, int range, int n_full, int n_reduced);
+
+/* ---- tuning / introspection (not part of the reference surface) --------- */
+/* Selects kernel variants for A/B measurements; key/value documented in
+ * DESIGN.md.  Unknown keys return F360_ERR_INVALID_ARG. */
+int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value);
+int f360_ctx_get_option(const f360_ctx *ctx, const char *key, int *value);
+
+/* Per-kernel timing with HIP events on the context's stream (what bench.py's
+ * roofline object is computed from).  f360_ctx_profile_arm(ctx, n) makes the
+ * next n transform calls record an event pair around each kernel they launch;
+ * f360_ctx_profile_read() waits for the recorded events and returns the
+ * accumulated time and launch count of one kernel id since the last reset. */
+int f360_kernel_count(void);
+const char *f360_kernel_name(int kernel_id);
+int f360_ctx_profile_arm(f360_ctx *ctx, int calls);
+int f360_ctx_profile_read(f360_ctx *ctx, int kernel_id, double *total_ms,
+                          int *launches);
+int f360_ctx_profile_reset(f360_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F360_H */

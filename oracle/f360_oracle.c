@@ -1,0 +1,591 @@
+/*
+ * f360_oracle.c -- CPU oracle (plain C) for the foveated-360 hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY -- see f360_oracle.h.  PARITY UNPINNED (no
+ * reference tests/goldens exist and the reference cannot be built or run in
+ * this environment); this is a restatement of the OpenCL C kernel text with
+ * OpenCL typing rules:
+ *   - unsuffixed floating literals are double; `f` literals are float;
+ *   - abs(int) yields unsigned; int op float promotes to float;
+ *   - (int) of a float / double truncates toward zero;
+ *   - convert_uchar3 (no _sat) of in-range values truncates;
+ *   - mix(a,b,t) = a + (b-a)*t, no fused multiply-add;
+ *   - uchar3 occupies 4 bytes; the 4th byte of a uchar3 store is unspecified
+ *     in OpenCL, here it is defined as 0.
+ * Build with -ffp-contract=off (oracle/Makefile does).
+ */
+#include "f360_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static int g_float_model = F360O_FLOAT_CR;
+
+void f360o_set_float_model(int model) { g_float_model = model; }
+int f360o_get_float_model(void) { return g_float_model; }
+
+/* OpenCL float builtins, modelled as correctly rounded (double, one rounding)
+ * unless the libm model is selected. */
+static float cl_expf(float x) {
+  return g_float_model ? expf(x) : (float)exp((double)x);
+}
+static float cl_powf(float x, float y) {
+  return g_float_model ? powf(x, y) : (float)pow((double)x, (double)y);
+}
+static float cl_logf(float x) {
+  return g_float_model ? logf(x) : (float)log((double)x);
+}
+static float cl_cosf(float x) {
+  return g_float_model ? cosf(x) : (float)cos((double)x);
+}
+static float cl_sinf(float x) {
+  return g_float_model ? sinf(x) : (float)sin((double)x);
+}
+static float cl_atanf(float x) {
+  return g_float_model ? atanf(x) : (float)atan((double)x);
+}
+static float cl_asinf(float x) {
+  return g_float_model ? asinf(x) : (float)asin((double)x);
+}
+static float cl_atan2f(float y, float x) {
+  return g_float_model ? atan2f(y, x) : (float)atan2((double)y, (double)x);
+}
+
+static int sgn_i(int v) { return (v > 0) - (v < 0); }
+static unsigned abs_u(int v) { return v < 0 ? 0u - (unsigned)v : (unsigned)v; }
+static int clamp_i(int v, int lo, int hi) {
+  /* OpenCL clamp(x,lo,hi) = min(max(x,lo),hi) */
+  int t = v > lo ? v : lo;
+  return t < hi ? t : hi;
+}
+static float clamp_f(float v, float lo, float hi) {
+  return fminf(fmaxf(v, lo), hi);
+}
+static float mix_f(float a, float b, float t) { return a + (b - a) * t; }
+
+/* ------------------------------------------------------------------------- */
+void f360o_lcg_fill(uint8_t *buf, size_t n, uint32_t seed) {
+  uint32_t s = seed;
+  for (size_t k = 0; k < n; ++k) {
+    s = s * 1664525u + 1013904223u;
+    buf[k] = (uint8_t)(s >> 24);
+  }
+}
+
+uint64_t f360o_fnv1a64(const void *buf, size_t n) {
+  const uint8_t *p = (const uint8_t *)buf;
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t k = 0; k < n; ++k) {
+    h ^= p[k];
+    h *= 0x100000001b3ull;
+  }
+  return h;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SAT encode.  Reference: copy_image_kernel (src/sat_encoder_encode_kernels.cl
+ * :1-20: bytes_per_pixel = linesize / width, first three bytes of each pixel
+ * widened to uint, row stride 3*width), scan_rows_kernel (:44-58) and
+ * scan_columns_kernel (:60-74); CPU twin src/sat_encoder.cc:137-185.  uint32
+ * addition is associative mod 2^32, so one row-major pass that carries the
+ * running row sum and adds the row above is bit-identical to the three
+ * passes. */
+void f360o_sat_encode(uint32_t *sat, const uint8_t *src, int width, int height,
+                      int linesize) {
+  const int bpp = linesize / width;
+  const size_t stride = (size_t)3 * (size_t)width;
+  for (int y = 0; y < height; ++y) {
+    const uint8_t *row = src + (size_t)y * (size_t)linesize;
+    uint32_t *out = sat + (size_t)y * stride;
+    const uint32_t *up = y ? out - stride : NULL;
+    uint32_t r = 0, g = 0, b = 0;
+    for (int x = 0; x < width; ++x) {
+      const uint8_t *px = row + (size_t)x * (size_t)bpp;
+      r += px[0];
+      g += px[1];
+      b += px[2];
+      if (up) {
+        out[3 * x + 0] = r + up[3 * x + 0];
+        out[3 * x + 1] = g + up[3 * x + 1];
+        out[3 * x + 2] = b + up[3 * x + 2];
+      } else {
+        out[3 * x + 0] = r;
+        out[3 * x + 1] = g;
+        out[3 * x + 2] = b;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Log-rectilinear radial offset, float flavour.
+ * src/sat_decoder_sample_rect_kernel.cl:266-273 (and :77-89 of the
+ * interpolate kernel, image_sampler_sample_rect_kernel.cl:73-80):
+ *   max((int)abs(u), (int)(lambda * (exp(pow((float)(2.0f*abs(u)/n), 4.0f)) - 1)))
+ */
+static float logrect_lambda(int full_size) {
+  return (float)full_size / (cl_expf(1.0f) - 1.0f);
+}
+static int logrect_f32(unsigned a, int n, float lambda) {
+  float t = 2.0f * (float)a / (float)n;
+  float e = cl_expf(cl_powf(t, 4.0f)) - 1.0f;
+  int v = (int)(lambda * e);
+  int ai = (int)a;
+  return ai > v ? ai : v;
+}
+/* double flavour: src/sat_decoder_interpolate_kernel.cl:56-65
+ *   (int)(lambda * (exp(pow(2.0 * abs(u) / n, 4.0)) - 1)) */
+static int logrect_f64(unsigned a, int n, float lambda) {
+  double t = 2.0 * (double)a / (double)n;
+  double e = exp(pow(t, 4.0)) - 1.0;
+  int v = (int)((double)lambda * e);
+  int ai = (int)a;
+  return ai > v ? ai : v;
+}
+
+/* One axis of create_grid_kernel (src/sat_decoder_sample_rect_kernel.cl
+ * :258-294): entry t -> i = t-1, u = i - n/2; midpoint of f(u) and f(u+1). */
+static void satdec_grid_axis(int16_t *g, int n_out, int n_src) {
+  const float lambda = logrect_lambda(n_src);
+  for (int t = 0; t <= n_out; ++t) {
+    int u = (t - 1) - n_out / 2;
+    int d = logrect_f32(abs_u(u), n_out, lambda) * sgn_i(u);
+    int dp = logrect_f32(abs_u(u + 1), n_out, lambda) * sgn_i(u + 1);
+    g[t] = (int16_t)floorf((float)(d + dp) / 2.0f);
+  }
+}
+
+void f360o_satdec_grid_axes(int16_t *gx, int16_t *gy, int out_w, int out_h,
+                            int src_w, int src_h) {
+  satdec_grid_axis(gx, out_w, src_w);
+  satdec_grid_axis(gy, out_h, src_h);
+}
+
+void f360o_satdec_grid(int16_t *grid, int out_w, int out_h, int src_w,
+                       int src_h) {
+  int16_t *gx = (int16_t *)malloc(sizeof(int16_t) * (size_t)(out_w + 1));
+  int16_t *gy = (int16_t *)malloc(sizeof(int16_t) * (size_t)(out_h + 1));
+  f360o_satdec_grid_axes(gx, gy, out_w, out_h, src_w, src_h);
+  const int gw = out_w + 1;
+  for (int ty = 0; ty <= out_h; ++ty)
+    for (int tx = 0; tx <= out_w; ++tx) {
+      grid[((size_t)ty * gw + tx) * 2 + 0] = gx[tx];
+      grid[((size_t)ty * gw + tx) * 2 + 1] = gy[ty];
+    }
+  free(gx);
+  free(gy);
+}
+
+/* sample_rect_kernel, src/sat_decoder_sample_rect_kernel.cl:138-241 */
+void f360o_satdec_sample_rect(uint8_t *dst, int out_w, int out_h,
+                              int out_linesize, const uint32_t *sat, int src_w,
+                              int src_h, const int16_t *grid, float cx,
+                              float cy) {
+  const int gls = (out_w + 1) * 2; /* grid row stride in shorts (:148-151) */
+  const int o_ls = out_linesize / 4; /* :154 */
+  const int cxp = (int)(cx * (float)src_w); /* :176 */
+  const int cyp = (int)(cy * (float)src_h);
+  for (int j = 0; j < out_h; ++j) {
+    for (int i = 0; i < out_w; ++i) {
+      int dx = grid[(size_t)(j + 1) * gls + (i + 1) * 2];     /* :168-169 */
+      int dxm = grid[(size_t)(j + 1) * gls + i * 2];          /* :170-171 */
+      int dy = grid[(size_t)(j + 1) * gls + (i + 1) * 2 + 1]; /* :172-173 */
+      int dym = grid[(size_t)j * gls + (i + 1) * 2 + 1];      /* :174-175 */
+      int px = cxp + dx, py = cyp + dy;
+      int mx = cxp + dxm, my = cyp + dym;
+      if (px >= src_w && mx >= src_w) { /* :181-187 */
+        px -= src_w;
+        mx -= src_w;
+      } else if (px < 0 && mx < 0) {
+        px += src_w;
+        mx += src_w;
+      }
+      int okx = (px >= 0 && px < src_w) || (mx >= 0 && mx < src_w);
+      int oky = (py >= 0 && py < src_h) || (my >= 0 && my < src_h);
+      if (!(okx && oky)) continue; /* :197-200, pixel left untouched */
+      px = clamp_i(px, 1, src_w - 1); /* :201-204 */
+      py = clamp_i(py, 1, src_h - 1);
+      mx = clamp_i(mx, 0, px - 1);
+      my = clamp_i(my, 0, py - 1);
+      uint8_t *o = dst + ((size_t)j * o_ls + i) * 4;
+      /* after the clamps px>0 && py>0 always holds, the other branches of
+       * :218-239 are unreachable */
+      const uint32_t *tl = sat + 3 * ((size_t)my * src_w + mx);
+      const uint32_t *tr = sat + 3 * ((size_t)my * src_w + px);
+      const uint32_t *bl = sat + 3 * ((size_t)py * src_w + mx);
+      const uint32_t *br = sat + 3 * ((size_t)py * src_w + px);
+      uint32_t area = (uint32_t)((px - mx) * (py - my));
+      for (int c = 0; c < 3; ++c)
+        o[c] = (uint8_t)((br[c] - tr[c] + tl[c] - bl[c]) / area);
+    }
+  }
+}
+
+/* decode_kernel, src/sat_decoder_decode_kernel.cl:1-58 */
+void f360o_satdec_decode(uint8_t *dst, int dst_linesize, const uint32_t *sat,
+                         int width, int height) {
+  const int tbpp = dst_linesize / width;
+  const size_t sl = (size_t)3 * width;
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      uint8_t *o = dst + (size_t)y * dst_linesize + (size_t)x * tbpp;
+      for (int c = 0; c < 3; ++c) {
+        uint32_t v;
+        if (x > 0 && y > 0)
+          v = (sat[y * sl + 3 * x + c] - sat[(y - 1) * sl + 3 * x + c] +
+               sat[(y - 1) * sl + 3 * (x - 1) + c] -
+               sat[y * sl + 3 * (x - 1) + c]) / 1u;
+        else if (x > 0)
+          v = (sat[y * sl + 3 * x + c] - sat[y * sl + 3 * (x - 1) + c]) / 1u;
+        else if (y > 0)
+          v = (sat[y * sl + 3 * x + c] - sat[(y - 1) * sl + 3 * x + c]) / 1u;
+        else
+          v = sat[c];
+        o[c] = (uint8_t)(v > 255u ? 255u : v);
+      }
+    }
+}
+
+/* interpolate_rect_kernel, src/sat_decoder_interpolate_kernel.cl:1-152 */
+void f360o_satdec_interpolate_rect(uint8_t *dst, int out_w, int out_h,
+                                   const uint8_t *src, int src_w, int src_h,
+                                   float cx, float cy) {
+  const int rw = src_w, rh = src_h;              /* :8-9 */
+  const float lx = logrect_lambda(out_w);        /* :11 */
+  const float ly = logrect_lambda(out_h);        /* :12 */
+  const int cxp = (int)(cx * (float)out_w);      /* :24 */
+  const int cyp = (int)(cy * (float)out_h);      /* :25 */
+  for (int y = 0; y < out_h; ++y) {
+    for (int x0 = 0; x0 < out_w; ++x0) {
+      int x = x0;
+      int x_offset = 0;
+      if (x - cxp > out_w / 2) { /* :27-33 */
+        x -= out_w;
+        x_offset = 1;
+      } else if (x - cxp < (-out_w) / 2) {
+        x += out_w;
+        x_offset = 1;
+      }
+      const int dx = x - cxp, dy = y - cyp;
+      /* :43-48  ceil(0.5 * rw * pow(log(abs(d)/lambda + 1), 0.25f)) * sgn */
+      int u = (int)(ceil(0.5 * (double)rw *
+                         (double)cl_powf(
+                             cl_logf((float)abs_u(dx) / lx + 1.0f), 0.25f)) *
+                    (double)sgn_i(dx));
+      int v = (int)(ceil(0.5 * (double)rh *
+                         (double)cl_powf(
+                             cl_logf((float)abs_u(dy) / ly + 1.0f), 0.25f)) *
+                    (double)sgn_i(dy));
+      if (abs_u(u) > abs_u(dx) || u == 0) u = dx; /* :50-55 */
+      if (abs_u(v) > abs_u(dy) || v == 0) v = dy;
+      const int dxc = logrect_f64(abs_u(u), rw, lx) * sgn_i(u); /* :56-65 */
+      const int dyc = logrect_f64(abs_u(v), rh, ly) * sgn_i(v);
+      uint8_t *o = dst + ((size_t)y * out_w + x0) * 4;
+      if (dxc == dx && dyc == dy) { /* :67-72 */
+        const uint8_t *s =
+            src + ((size_t)clamp_i(v + rh / 2, 0, src_h - 1) * src_w +
+                   clamp_i(u + rw / 2, 0, src_w - 1)) * 4;
+        o[0] = s[0];
+        o[1] = s[1];
+        o[2] = s[2];
+        o[3] = 0;
+        continue;
+      }
+      const int du = (x < cxp) - (x > cxp); /* :75-76 */
+      const int dv = (y < cyp) - (y > cyp);
+      const int dxm = logrect_f32(abs_u(u + du), rw, lx) * sgn_i(u); /* :77-83 */
+      const int dym = logrect_f32(abs_u(v + dv), rh, ly) * sgn_i(v); /* :84-89 */
+      const int a0 = cxp + dxm, a1 = cxp + dxc;
+      const int b0 = cyp + dym, b1 = cyp + dyc;
+      const int min_x = a0 < a1 ? a0 : a1, max_x = a0 > a1 ? a0 : a1;
+      const int min_y = b0 < b1 ? b0 : b1, max_y = b0 > b1 ? b0 : b1;
+      int min_u = u < u + du ? u : u + du, max_u = u > u + du ? u : u + du;
+      int min_v = v < v + dv ? v : v + dv, max_v = v > v + dv ? v : v + dv;
+      if (min_x < 0 && !x_offset) min_u = max_u;        /* :105-116 */
+      if (max_x >= out_w && !x_offset) max_u = min_u;
+      if (min_y < 0) min_v = max_v;
+      if (max_y >= out_h) max_v = min_v;
+      const int r0 = clamp_i(min_v + rh / 2, 0, src_h - 1);
+      const int r1 = clamp_i(max_v + rh / 2, 0, src_h - 1);
+      const int c0 = clamp_i(min_u + rw / 2, 0, src_w - 1);
+      const int c1 = clamp_i(max_u + rw / 2, 0, src_w - 1);
+      const uint8_t *tl = src + ((size_t)r0 * src_w + c0) * 4;
+      const uint8_t *tr = src + ((size_t)r0 * src_w + c1) * 4;
+      const uint8_t *bl = src + ((size_t)r1 * src_w + c0) * 4;
+      const uint8_t *br = src + ((size_t)r1 * src_w + c1) * 4;
+      const float yr =
+          max_y == min_y
+              ? 0.0f
+              : clamp_f((float)(y - min_y) / (float)(max_y - min_y), 0.0f, 1.0f);
+      const float xr =
+          max_x == min_x
+              ? 0.0f
+              : clamp_f((float)(x - min_x) / (float)(max_x - min_x), 0.0f, 1.0f);
+      for (int c = 0; c < 3; ++c) {
+        float l = mix_f((float)tl[c], (float)bl[c], yr);
+        float r = mix_f((float)tr[c], (float)br[c], yr);
+        o[c] = (uint8_t)(int)mix_f(l, r, xr);
+      }
+      o[3] = 0;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* ImageSampler create_grid_kernel, src/image_sampler_sample_rect_kernel.cl
+ * :48-88; Wr x Hr entries, row stride Wr (grid_linesize = 2*Wr shorts). */
+void f360o_is_grid(int16_t *grid, int out_w, int out_h, int src_w, int src_h) {
+  const float lx = logrect_lambda(src_w), ly = logrect_lambda(src_h);
+  for (int j = 0; j < out_h; ++j) {
+    int v = j - out_h / 2;
+    int16_t gy = (int16_t)(logrect_f32(abs_u(v), out_h, ly) * sgn_i(v));
+    for (int i = 0; i < out_w; ++i) {
+      int u = i - out_w / 2;
+      grid[((size_t)j * out_w + i) * 2 + 0] =
+          (int16_t)(logrect_f32(abs_u(u), out_w, lx) * sgn_i(u));
+      grid[((size_t)j * out_w + i) * 2 + 1] = gy;
+    }
+  }
+}
+
+/* ImageSampler sample_rect_kernel, :1-46 */
+void f360o_is_sample_rect(uint8_t *dst, int out_w, int out_h, int out_linesize,
+                          const uint8_t *src, int src_w, int src_h,
+                          int src_linesize, const int16_t *grid, float cx,
+                          float cy) {
+  const int sbpp = src_linesize / src_w, obpp = out_linesize / out_w;
+  for (int j = 0; j < out_h; ++j)
+    for (int i = 0; i < out_w; ++i) {
+      int dx = grid[((size_t)j * out_w + i) * 2 + 0];
+      int dy = grid[((size_t)j * out_w + i) * 2 + 1];
+      int xp = (int)(cx * (float)src_w + (float)dx); /* :24 float add */
+      int yp = (int)(cy * (float)src_h + (float)dy);
+      if (xp >= src_w)
+        xp -= src_w;
+      else if (xp < 0)
+        xp += src_w;
+      if (xp >= 0 && xp < src_w && yp >= 0 && yp < src_h) {
+        uint8_t *o = dst + (size_t)j * out_linesize + (size_t)i * obpp;
+        const uint8_t *s = src + (size_t)yp * src_linesize + (size_t)xp * sbpp;
+        o[0] = s[0];
+        o[1] = s[1];
+        o[2] = s[2];
+      }
+    }
+}
+
+/* create_logpolar_grid_kernel, src/image_sampler_sample_logpolar_kernel.cl
+ * :5-39.  _PI is the double literal 3.14159265359, _ALPHA 1.0. */
+#define LP_PI 3.14159265359
+static float lp_radius(int i, int n) { /* exp(10.0f * pow((float)i / n, 1.0f)) */
+  return cl_expf(10.0f * cl_powf((float)i / (float)n, 1.0f));
+}
+void f360o_is_logpolar_grid(int16_t *grid, int out_w, int out_h, int src_w,
+                            int src_h) {
+  (void)src_w;
+  (void)src_h;
+  for (int j = 0; j < out_h; ++j) {
+    float ang = (float)((double)((float)j / (float)out_h * 2.0f) * LP_PI);
+    float cs = cl_cosf(ang), sn = cl_sinf(ang);
+    for (int i = 0; i < out_w; ++i) {
+      float r = lp_radius(i, out_w);
+      grid[((size_t)j * out_w + i) * 2 + 0] = (int16_t)(int)(r * cs);
+      grid[((size_t)j * out_w + i) * 2 + 1] = (int16_t)(int)(r * sn);
+    }
+  }
+}
+
+/* sample_logpolar_kernel, :41-86 */
+void f360o_is_sample_logpolar(uint8_t *dst, int out_w, int out_h,
+                              int out_linesize, const uint8_t *src, int src_w,
+                              int src_h, int src_linesize, const int16_t *grid,
+                              float cx, float cy) {
+  const int sbpp = src_linesize / src_w, obpp = out_linesize / out_w;
+  for (int j = 0; j < out_h; ++j)
+    for (int i = 0; i < out_w; ++i) {
+      int xp = (int)(cx * (float)src_w +
+                     (float)grid[((size_t)j * out_w + i) * 2 + 0]);
+      int yp = (int)(cy * (float)src_h +
+                     (float)grid[((size_t)j * out_w + i) * 2 + 1]);
+      xp = (xp + 10 * src_w) % src_w;
+      yp = clamp_i(yp, 0, src_h - 1);
+      if (xp >= 0 && xp < src_w && yp >= 0 && yp < src_h) {
+        uint8_t *o = dst + (size_t)j * out_linesize + (size_t)i * obpp;
+        const uint8_t *s = src + (size_t)yp * src_linesize + (size_t)xp * sbpp;
+        o[0] = s[0];
+        o[1] = s[1];
+        o[2] = s[2];
+      }
+    }
+}
+
+/* interpolate_logpolar_kernel, src/image_sampler_interpolate_kernel.cl:1-81 */
+void f360o_is_interpolate_logpolar(uint8_t *dst, int out_w, int out_h,
+                                   const uint8_t *src, int src_w, int src_h,
+                                   float cx, float cy) {
+  const int rw = src_w, rh = src_h;
+  const int cxp = (int)(cx * (float)out_w), cyp = (int)(cy * (float)out_h);
+  for (int y = 0; y < out_h; ++y)
+    for (int x0 = 0; x0 < out_w; ++x0) {
+      int x = x0;
+      if (x - cxp > out_w / 2)
+        x -= out_w;
+      else if (x - cxp < (-out_w) / 2)
+        x += out_w;
+      const int dx = x - cxp, dy = y - cyp;
+      float i_f;
+      if (dx == 0 && dy == 0) {
+        i_f = 0.0f;
+      } else {
+        float r2 = cl_powf((float)dx, 2.0f) + cl_powf((float)dy, 2.0f);
+        i_f = (float)rw * cl_powf(cl_logf(sqrtf(r2)) / 10.0f, 1.0f / 1.0f);
+      }
+      const int i = clamp_i((int)roundf(i_f), 0, rw - 1);
+      float j_f;
+      if (dx != 0) {
+        j_f = (float)(((double)cl_atanf((float)dy / (float)dx) +
+                       M_PI * (double)(dx < 0)) *
+                      ((double)(float)rh / (2.0 * M_PI)));
+        j_f = fmodf(j_f + (float)(2 * rh), (float)src_h);
+      } else {
+        j_f = (float)((M_PI_2 + M_PI * (double)(dy < 0)) *
+                      ((double)rh / (2.0 * M_PI)));
+      }
+      const int j = clamp_i((int)roundf(j_f), 0, rh - 1);
+      const float rad = lp_radius(i, src_w);
+      const double ang = (double)((float)j / (float)src_h * 2.0f) * M_PI;
+      const int calc_x =
+          (int)((double)(cx * (float)out_w) + (double)rad * cos(ang));
+      const int calc_y =
+          (int)((double)(cy * (float)out_h) + (double)rad * sin(ang));
+      uint8_t *o = dst + ((size_t)y * out_w + x0) * 4;
+      if (calc_x == x && calc_y == y) {
+        const uint8_t *s = src + ((size_t)j * src_w + i) * 4;
+        o[0] = s[0];
+        o[1] = s[1];
+        o[2] = s[2];
+        o[3] = 0;
+        continue;
+      }
+      const int min_i = clamp_i((int)floorf(i_f), 0, src_w - 1);
+      const int min_j = (int)floorf(j_f + (float)src_h) % src_h;
+      const int max_i = clamp_i((int)ceilf(i_f), 0, src_w - 1);
+      const int max_j = (int)ceilf(j_f + (float)src_h) % src_h;
+      const uint8_t *tl = src + ((size_t)min_j * src_w + min_i) * 4;
+      const uint8_t *tr = src + ((size_t)min_j * src_w + max_i) * 4;
+      const uint8_t *bl = src + ((size_t)max_j * src_w + min_i) * 4;
+      const uint8_t *br = src + ((size_t)max_j * src_w + max_i) * 4;
+      const float ir = i_f - floorf(i_f), jr = j_f - floorf(j_f);
+      for (int c = 0; c < 3; ++c) {
+        float l = mix_f((float)tl[c], (float)bl[c], jr);
+        float r = mix_f((float)tr[c], (float)br[c], jr);
+        o[c] = (uint8_t)(int)mix_f(l, r, ir);
+      }
+      o[3] = 0;
+    }
+}
+
+/* logpolar_gaussian_blur_kernel, :88-142 */
+void f360o_is_logpolar_blur(uint8_t *dst, int w, int h, const uint8_t *src) {
+  const float P1 = (float)0.3377, P2 = (float)0.1217, P3 = (float)0.0439;
+  for (int j = 0; j < h; ++j)
+    for (int i = 0; i < w; ++i) {
+      uint8_t *o = dst + ((size_t)j * w + i) * 4;
+      if (i < w / 2) {
+        const uint8_t *s = src + ((size_t)j * w + i) * 4;
+        o[0] = s[0];
+        o[1] = s[1];
+        o[2] = s[2];
+        o[3] = 0;
+        continue;
+      }
+      const int jm = j - 1 > 0 ? j - 1 : 0, jp = j + 1 < h - 1 ? j + 1 : h - 1;
+      const int im = i - 1 > 0 ? i - 1 : 0, ip = i + 1 < w - 1 ? i + 1 : w - 1;
+#define TX(J, I) ((float)src[((size_t)(J) * w + (I)) * 4 + c])
+      for (int c = 0; c < 3; ++c) {
+        float corners = TX(jm, im) + TX(jm, ip) + TX(jp, im) + TX(jp, ip);
+        float edges = TX(jm, i) + TX(j, im) + TX(j, ip) + TX(jp, i);
+        float v = P3 * corners + P2 * edges + P1 * TX(j, i);
+        o[c] = (uint8_t)(int)v;
+      }
+#undef TX
+      o[3] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* gnomonic_kernel, src/projections_program.cl:7-47 */
+#define G_PI 3.141592653589793
+#define G_PI_2 1.5707963267948966
+void f360o_gnomonic(uint8_t *dst, int dst_w, int dst_h, const uint8_t *src,
+                    int src_w, int src_h, float cx, float cy) {
+  const float phi1 = (float)(((double)cy - 0.5) * G_PI);
+  const float lambda0 = (float)(((double)cx - 0.5) * 2.0 * G_PI);
+  const float sp1 = cl_sinf(phi1), cp1 = cl_cosf(phi1);
+  for (int j = 0; j < dst_h; ++j)
+    for (int i = 0; i < dst_w; ++i) {
+      float x = 6.0f * ((float)i / (float)dst_w - 0.5f);
+      float y = 3.0f * ((float)j / (float)dst_h - 0.5f);
+      float rho = sqrtf(x * x + y * y);
+      float c = cl_atanf(rho);
+      float sc = cl_sinf(c), cc = cl_cosf(c);
+      float phi = cl_asinf(cc * sp1 + (y * sc * cp1) / rho);
+      float lam = lambda0 + cl_atan2f(x * sc, rho * cp1 * cc - y * sp1 * sc);
+      phi = (float)fmod((double)phi + G_PI_2 + 10 * G_PI, 2 * G_PI);
+      lam = (float)fmod((double)lam + G_PI + 10 * G_PI, 2 * G_PI);
+      float su = (float)((double)lam / (2.0 * G_PI));
+      float sv = (float)((double)phi / (G_PI));
+      su = clamp_f(su, 0.0f, 0.999f); /* NaN (rho == 0) clamps to 0 */
+      sv = clamp_f(sv, 0.0f, 0.999f);
+      size_t sc_idx =
+          (size_t)(int)(sv * (float)src_h) * src_w + (int)(su * (float)src_w);
+      const uint8_t *s = src + sc_idx * 4;
+      uint8_t *o = dst + ((size_t)j * dst_w + i) * 4;
+      o[0] = s[0];
+      o[1] = s[1];
+      o[2] = s[2];
+      o[3] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+uint64_t f360o_pipeline_encode_sample(int frames, int src_w, int src_h,
+                                      int out_w, int out_h, uint32_t seed0,
+                                      double *seconds_out) {
+  const size_t fbytes = (size_t)4 * src_w * src_h;
+  const size_t obytes = (size_t)4 * out_w * out_h;
+  uint8_t *frame = (uint8_t *)malloc(fbytes);
+  uint32_t *sat = (uint32_t *)malloc((size_t)12 * src_w * src_h);
+  uint8_t *red = (uint8_t *)calloc(obytes, 1);
+  int16_t *grid =
+      (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)(out_w + 1) * (out_h + 1));
+  f360o_satdec_grid(grid, out_w, out_h, src_w, src_h);
+  uint64_t digest = 0xcbf29ce484222325ull;
+  double t = 0.0;
+  for (int k = 0; k < frames; ++k) {
+    f360o_lcg_fill(frame, fbytes, seed0 + (uint32_t)k);
+    float gx = (float)(0.5 + 0.45 * sin(2.0 * M_PI * (double)k / 97.0));
+    float gy = (float)(0.5 + 0.35 * sin(2.0 * M_PI * (double)k / 61.0));
+    double t0 = now_s();
+    f360o_sat_encode(sat, frame, src_w, src_h, 4 * src_w);
+    f360o_satdec_sample_rect(red, out_w, out_h, 4 * out_w, sat, src_w, src_h,
+                             grid, gx, gy);
+    t += now_s() - t0;
+    digest ^= f360o_fnv1a64(red, obytes);
+    digest *= 0x100000001b3ull;
+  }
+  if (seconds_out) *seconds_out = t;
+  free(frame);
+  free(sat);
+  free(red);
+  free(grid);
+  return digest;
+}
