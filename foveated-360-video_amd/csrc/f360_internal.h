@@ -90,8 +90,9 @@ struct f360_ctx {
   // options (f360_ctx_set_option)
   int opt_band_rows = 32;      // "sat.band_rows": 16 | 32 | 64
   int opt_sb_bands = 8;        // "sat.sb_bands"
-  int opt_store_mode = 0;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-transposed
+  int opt_store_mode = 1;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-staged contiguous stores
   int opt_sample_variant = 0;  // "sample.variant": 0 per-pixel, 1 column walker
+  int opt_walk_rows = 32;      // "sample.rows": reduced rows per wave of the column walker
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;

@@ -243,6 +243,7 @@ static const OptionSlot kOptions[] = {
     {"sat.store", &f360_ctx::opt_store_mode},
     {"sat.reverse", &f360_ctx::opt_reverse_tiles},
     {"sample.variant", &f360_ctx::opt_sample_variant},
+    {"sample.rows", &f360_ctx::opt_walk_rows},
 };
 
 int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
@@ -255,6 +256,8 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
       if (s.field == &f360_ctx::opt_sb_bands)
         F360_REQUIRE(value >= 1 && value <= 64, "sat.sb_bands out of range: %d",
                      value);
+      if (s.field == &f360_ctx::opt_walk_rows)
+        F360_REQUIRE(value >= 1 && value <= 4096, "sample.rows out of range: %d", value);
       ctx->*(s.field) = value;
       return F360_OK;
     }

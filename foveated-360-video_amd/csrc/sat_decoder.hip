@@ -85,6 +85,79 @@ __global__ __launch_bounds__(256) void sample_rect_kernel(
   o[2] = (uint8_t)udiv_exact(br.z - tr.z + tl.z - bl.z, area);
 }
 
+// Variant 1 ("column walker"): a wave owns 63 adjacent reduced columns (lane 0
+// is a halo lane for the column to the left) and walks down `rows` reduced rows.
+// Adjacent boxes share corners -- the lower-left corner of pixel i is the
+// lower-right corner of pixel i-1, and the top corners of row j are the bottom
+// corners of row j-1 -- so each output pixel costs ONE 12-byte gather: the left
+// corner arrives by DPP from the neighbouring lane and the top corners stay in
+// registers.  Where the reference's wrap / clamp rules break that sharing
+// (frame seam, first row of a run) the corner is loaded explicitly, so the
+// result is the reference's for every pixel.
+__device__ __forceinline__ uint32_t dpp_from_lane_below(uint32_t v) {
+  // wave_shr:1 -- lane l receives lane l-1's value, lane 0 keeps its own
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint3 dpp_from_lane_below(const uint3 &v) {
+  return make_uint3(dpp_from_lane_below(v.x), dpp_from_lane_below(v.y),
+                    dpp_from_lane_below(v.z));
+}
+
+constexpr int kWalkCols = 63;
+
+__global__ __launch_bounds__(256) void sample_rect_walk_kernel(
+    uint8_t *__restrict__ dst, int out_w, int out_h, int out_stride_px,
+    const uint32_t *__restrict__ sat, int src_w, int src_h,
+    const int16_t *__restrict__ gx, const int16_t *__restrict__ gy, int cxp,
+    int cyp, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int c0 = __builtin_amdgcn_readfirstlane(
+      ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kWalkCols);
+  if (c0 >= out_w) return;  // whole wave
+  const int i = c0 - 1 + lane;
+  const int ic = min(max(i, 0), out_w - 1);
+  const AxisBox bx = sample_axis(cxp, gx[ic + 1], gx[ic], src_w, true);
+  const bool writes = lane > 0 && i < out_w && bx.ok;
+  const bool left_shared =
+      lane > 0 && dpp_from_lane_below((uint32_t)bx.hi) == (uint32_t)bx.lo;
+  const uint32_t dxw = (uint32_t)(bx.hi - bx.lo);
+
+  const int j0 = blockIdx.y * rows, j1 = min(j0 + rows, out_h);
+  int prev_hi = -1;
+  uint3 p_br = make_uint3(0, 0, 0), p_bl = make_uint3(0, 0, 0);
+  for (int j = j0; j < j1; ++j) {
+    const AxisBox by = sample_axis(cyp, gy[j + 1], gy[j], src_h, false);  // wave-uniform
+    if (!by.ok) {
+      prev_hi = -1;
+      continue;
+    }
+    const uint3 br = load_sat3(sat, (size_t)by.hi * src_w + bx.hi);
+    uint3 bl = dpp_from_lane_below(br);
+    if (!left_shared) bl = load_sat3(sat, (size_t)by.hi * src_w + bx.lo);
+    uint3 tr, tl;
+    if (by.lo == prev_hi) {
+      tr = p_br;
+      tl = p_bl;
+    } else {
+      tr = load_sat3(sat, (size_t)by.lo * src_w + bx.hi);
+      tl = dpp_from_lane_below(tr);
+      if (!left_shared) tl = load_sat3(sat, (size_t)by.lo * src_w + bx.lo);
+    }
+    if (writes) {
+      const uint32_t area = dxw * (uint32_t)(by.hi - by.lo);
+      uint8_t *o = dst + ((size_t)j * out_stride_px + i) * 4;
+      const uint32_t r = udiv_exact(br.x - tr.x + tl.x - bl.x, area);
+      const uint32_t g = udiv_exact(br.y - tr.y + tl.y - bl.y, area);
+      const uint32_t b = udiv_exact(br.z - tr.z + tl.z - bl.z, area);
+      *reinterpret_cast<uint16_t *>(o) = (uint16_t)((r & 0xffu) | ((g & 0xffu) << 8));
+      o[2] = (uint8_t)b;
+    }
+    p_br = br;
+    p_bl = bl;
+    prev_hi = by.hi;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // decode_kernel (src/sat_decoder_decode_kernel.cl:1-58): 1x1 boxes.
 __global__ __launch_bounds__(256) void decode_kernel(
@@ -317,7 +390,17 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   const int cyp = (int)(center_y * (float)source_height);
   f360_ctx *ctx = dec->ctx;
   const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
-  {
+  if (ctx->opt_sample_variant == 1) {
+    const int rows = ctx->opt_walk_rows;
+    const dim3 wgrid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),
+                     (target_height + rows - 1) / rows);
+    f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
+    hipLaunchKernelGGL(sample_rect_walk_kernel, wgrid, dim3(256), 0, ctx->stream,
+                       target_dev, target_width, target_height,
+                       target_linesize / 4, sat_dev, source_width, source_height,
+                       dec->gx_dev.as<int16_t>(), dec->gy_dev.as<int16_t>(), cxp,
+                       cyp, rows);
+  } else {
     f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
     hipLaunchKernelGGL(sample_rect_kernel, grid, dim3(256), 0, ctx->stream,
                        target_dev, target_width, target_height,

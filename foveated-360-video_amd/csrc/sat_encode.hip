@@ -48,6 +48,25 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
   return v;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS byte address in, 16 bytes per lane.  The reads carry their own wait
+// (hipcc does not count memory operations issued from inline asm).
+__device__ __forceinline__ void lds_write_b128(uint32_t addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read3_b128(uint32_t addr, u32x4 &a, u32x4 &b,
+                                               u32x4 &c) {
+  asm volatile(
+      "ds_read_b128 %0, %3\n\t"
+      "ds_read_b128 %1, %3 offset:1024\n\t"
+      "ds_read_b128 %2, %3 offset:2048\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c)
+      : "v"(addr)
+      : "memory");
+}
+
 struct EncodeArgs {
   uint32_t *sat;
   const uint8_t *src;
@@ -105,35 +124,68 @@ __device__ __forceinline__ void load12(const uint32_t *src, uint32_t (&a)[12]) {
 }
 
 // ---- K1: column / row / tile sums ------------------------------------------
+// One workgroup (4 waves) per (strip, super-band).  Every band's rows are
+// split into four contiguous quarters, one per wave, so four times as many
+// loads are in flight as with one wave per tile; the waves' running column
+// sums meet in LDS once per band.
 template <bool VEC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
     const EncodeArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t part[2][kWavesPerBlock][64 * 12];
+  __shared__ uint32_t tpart[2][kWavesPerBlock][4];
   const int lane = threadIdx.x & 63;
-  const int strip = __builtin_amdgcn_readfirstlane(
-      (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int strip = blockIdx.x;
   const int sb = blockIdx.y;
-  if (strip >= a.nstrips) return;
   const int x0 = strip * kStripPx + lane * kLanePx;
+  const int quarter = a.band_rows / kWavesPerBlock;
 
-  uint32_t col[12];
+  uint32_t col[12];  // this wave's rows only, since the start of the super-band
 #pragma unroll
   for (int e = 0; e < 12; ++e) col[e] = 0;
 
-  const int band_end = min((sb + 1) * a.sb_bands, a.nbands);
-  for (int band = sb * a.sb_bands; band < band_end; ++band) {
-    store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, col);
-    const int y_end = min((band + 1) * a.band_rows, a.height);
-    uint32_t tile_rg = 0, tile_b = 0, tile_g_hi = 0;  // lane 63 only
-    for (int y = band * a.band_rows; y < y_end; y += kRowUnroll) {
+  const int band0 = sb * a.sb_bands;
+  const int band_end = min(band0 + a.sb_bands, a.nbands);
+  // iteration `band_end` only publishes the super-band totals
+  for (int band = band0; band <= band_end; ++band) {
+    const int buf = (band - band0) & 1;
+    store12(&part[buf][wave][lane * 12], col);
+    __syncthreads();
+    if (wave == ((band - band0) & 3)) {
+      uint32_t sum[12], t[12];
+      load12(&part[buf][0][lane * 12], sum);
+#pragma unroll
+      for (int w = 1; w < kWavesPerBlock; ++w) {
+        load12(&part[buf][w][lane * 12], t);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) sum[e] += t[e];
+      }
+      uint32_t *dst = (band < band_end ? a.lp + (size_t)band * a.wp3
+                                       : a.sbtotal + (size_t)sb * a.wp3) +
+                      (size_t)x0 * 3;
+      store12(dst, sum);
+      if (band > band0 && lane < 3) {  // previous band's tile total
+        const int pb = buf ^ 1;
+        a.tiletotal[((size_t)strip * a.nbands + (band - 1)) * 3 + lane] =
+            tpart[pb][0][lane] + tpart[pb][1][lane] + tpart[pb][2][lane] +
+            tpart[pb][3][lane];
+      }
+    }
+    if (band == band_end) break;
+
+    const int y_lo = band * a.band_rows + wave * quarter;
+    const int y_hi = min(min(y_lo + quarter, (band + 1) * a.band_rows), a.height);
+    uint32_t tile_r = 0, tile_g = 0, tile_b = 0;  // lane 63 only
+    for (int y = y_lo; y < y_hi; y += kRowUnroll) {
       uint4 raw[kRowUnroll];
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r)
-        raw[r] = (y + r < y_end)
+        raw[r] = (y + r < y_hi)
                      ? load_px4<VEC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
                      : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r) {
-        if (y + r >= y_end) break;
+        if (y + r >= y_hi) break;
         uint32_t c[12];
         unpack_px4(raw[r], c);
 #pragma unroll
@@ -149,20 +201,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
           rs[0] = inc_rg & 0xffffu;
           rs[1] = inc_rg >> 16;
           rs[2] = inc_b;
-          tile_rg += inc_rg & 0xffffu;
-          tile_g_hi += inc_rg >> 16;
+          tile_r += inc_rg & 0xffffu;
+          tile_g += inc_rg >> 16;
           tile_b += inc_b;
         }
       }
     }
     if (lane == 63) {
-      uint32_t *tt = a.tiletotal + ((size_t)strip * a.nbands + band) * 3;
-      tt[0] = tile_rg;
-      tt[1] = tile_g_hi;
-      tt[2] = tile_b;
+      tpart[buf][wave][0] = tile_r;
+      tpart[buf][wave][1] = tile_g;
+      tpart[buf][wave][2] = tile_b;
     }
   }
-  store12(a.sbtotal + (size_t)sb * a.wp3 + (size_t)x0 * 3, col);
 }
 
 // ---- K2: exclusive prefixes of the carry arrays ------------------------------
@@ -302,16 +352,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
       if (VEC && STORE == 0) {
         if (x0 < a.width) store12(row + (size_t)x0 * 3, acc);
       } else if (VEC && STORE == 1) {
-        uint32_t *mine = stage + wave * 3 * kStripPx;
-        store12(mine + lane * 12, acc);
+        // Lanes exchange data through wave-private LDS.  One wave's LDS
+        // operations execute in order, so no s_barrier is needed; the accesses
+        // are inline asm because the compiler's memory model is per lane (it
+        // deletes plain LDS stores that only OTHER lanes read back).
+        const uint32_t mine =
+            (uint32_t)reinterpret_cast<uintptr_t>(stage) + wave * 3 * kStripPx * 4;
+        lds_write_b128(mine + lane * 48, u32x4{acc[0], acc[1], acc[2], acc[3]});
+        lds_write_b128(mine + lane * 48 + 16, u32x4{acc[4], acc[5], acc[6], acc[7]});
+        lds_write_b128(mine + lane * 48 + 32, u32x4{acc[8], acc[9], acc[10], acc[11]});
+        u32x4 v[3];
+        lds_read3_b128(mine + lane * 16, v[0], v[1], v[2]);
         const int row_dwords = a.width * 3;
         const int base = strip * kStripPx * 3;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           const int off = q * 256 + lane * 4;
-          const uint4 v = *reinterpret_cast<const uint4 *>(mine + off);
           if (base + off < row_dwords)  // width % 4 == 0 -> whole 16 B in range
-            *reinterpret_cast<uint4 *>(row + base + off) = v;
+            *reinterpret_cast<u32x4 *>(row + base + off) = v[q];
         }
       } else {
 #pragma unroll
@@ -421,10 +479,10 @@ extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
   {
     f360::KernelSpan span(ctx, f360::kSatReduce, prof);
     if (vec)
-      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(bx, p.nsb), block, 0,
+      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(p.nstrips, p.nsb), block, 0,
                          ctx->stream, a);
     else
-      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(bx, p.nsb), block, 0,
+      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(p.nstrips, p.nsb), block, 0,
                          ctx->stream, a);
   }
 

@@ -1,0 +1,100 @@
+// f360/sat_decoder.h -- drop-in for the reference's src/sat_decoder.h:20-83
+// (device methods).  The AVCodecContext* parameter of SampleFrameRectGPU is a
+// template: the reference reads only ->width / ->height (src/sat_decoder.cc
+// :328-329), so a real AVCodecContext or any struct with those fields works.
+// Not provided: the CPU twins (oracle/ holds the CPU restatement, as test
+// infrastructure) and the experimental SVD pair CreateReducedSAT /
+// SampleFrameFromReducedSAT and SampleFrameRectGPU360 (no caller in the
+// reference; SURVEY.md 2.1 #2f, 2.2).
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+
+#include "opencl_manager.h"
+
+class SATDecoder {
+ private:
+  OpenCLManager *cl_manager = nullptr;
+  f360_sat_decoder *impl = nullptr;
+  bool use_opencl = false;
+
+  SATDecoder(const SATDecoder &) = delete;
+  SATDecoder &operator=(const SATDecoder &) = delete;
+
+ public:
+  SATDecoder() = default;  // src/sat_decoder.cc:4
+  explicit SATDecoder(OpenCLManager *manager) : cl_manager(manager) {  // :6-127
+    if (manager && f360_satdec_create(manager->context.get(), &impl) == F360_OK) {
+      use_opencl = true;
+    } else if (manager) {
+      std::cerr << "Failed to create decoder state: " << f360_last_error_string() << std::endl;
+      exit(EXIT_FAILURE);  // the reference exits when its programs fail to build (:41-62)
+    }
+  }
+  ~SATDecoder() { f360_satdec_destroy(impl); }
+
+  // src/sat_decoder.cc:139-174
+  void InitializeGrid(int target_width, int target_height, int source_width, int source_height) {
+    if (!use_opencl) return;
+    const int ret = f360_satdec_initialize_grid(impl, target_width, target_height, source_width,
+                                                source_height);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::InitializeGrid] Launch Kernel Failed; " << ret << std::endl;
+  }
+
+  // src/sat_decoder.cc:176-210 (the reference launch always fails with work_dim 0; this runs)
+  void DecodeFrameGPU(cl_mem cl_target_buffer, int target_linesize, cl_mem cl_source_buffer,
+                      int width, int height) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::DecodeFrameGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_decode(impl, static_cast<uint8_t *>(cl_target_buffer),
+                                       target_linesize,
+                                       static_cast<const uint32_t *>(cl_source_buffer), width,
+                                       height);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::DecodeFrameGPU] decode kernel launch failed:" << ret << std::endl;
+  }
+
+  // src/sat_decoder.cc:301-348
+  template <class CodecContext>
+  void SampleFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
+                          int target_linesize, cl_mem cl_source_buffer, CodecContext *codec_ctx,
+                          float center_x, float center_y) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::SampleFrameRectGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_sample_rect(
+        impl, static_cast<uint8_t *>(cl_target_buffer), target_width, target_height,
+        target_linesize, static_cast<const uint32_t *>(cl_source_buffer), codec_ctx->width,
+        codec_ctx->height, center_x, center_y);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::SampleFrameRectGPU] Sample rect kernel launch failed:" << ret
+                << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
+  // src/sat_decoder.cc:887-928
+  void InterpolateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
+                               int target_linesize, cl_mem cl_source_buffer, int source_width,
+                               int source_height, int source_linesize, float center_x,
+                               float center_y) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::InterpolateFrameRectGPU] Not initialized with OpenCL"
+                << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_interpolate_rect(
+        impl, static_cast<uint8_t *>(cl_target_buffer), target_width, target_height,
+        target_linesize, static_cast<const uint8_t *>(cl_source_buffer), source_width,
+        source_height, source_linesize, center_x, center_y);
+    if (ret != F360_OK) {
+      std::cerr << "[SATDecoder::InterpolateFrameRectGPU] interpolate kernel launch failed:"
+                << ret << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
+      exit(EXIT_FAILURE);  // :924
+    }
+  }
+};

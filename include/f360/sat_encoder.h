@@ -1,0 +1,38 @@
+// f360/sat_encoder.h -- drop-in for the reference's src/sat_encoder.h:22-43.
+// Same class name, constructors and GPU method signature; the body calls the
+// HIP engine through the C ABI.  EncodeFrameCPU is not provided: the product
+// path has no CPU implementation (the CPU restatement lives under oracle/ and
+// is test infrastructure).
+#pragma once
+
+#include <cstdint>
+#include <iostream>
+
+#include "opencl_manager.h"
+
+class SATEncoder {
+ private:
+  bool use_OpenCL = false;
+  OpenCLManager *cl_manager = nullptr;
+
+ public:
+  SATEncoder() = default;                               // src/sat_encoder.cc:3
+  explicit SATEncoder(OpenCLManager *manager)           // src/sat_encoder.cc:5-52
+      : use_OpenCL(manager != nullptr), cl_manager(manager) {}
+
+  // src/sat_encoder.cc:67-135.  Asynchronous: enqueues on the manager's queue.
+  void EncodeFrameGPU(cl_mem cl_target_buffer, cl_mem cl_source_buffer, int source_width,
+                      int source_height, int source_linesize) {
+    if (!use_OpenCL) {
+      std::cerr << "[SATEncoder::EncodeFrameGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_sat_encode(cl_manager->context.get(),
+                                    static_cast<uint32_t *>(cl_target_buffer),
+                                    static_cast<const uint8_t *>(cl_source_buffer), source_width,
+                                    source_height, source_linesize);
+    if (ret != F360_OK)
+      std::cerr << "[SATEncoder::EncodeFrameGPU] kernel launch failed:" << ret << " "
+                << f360_last_error_string() << std::endl;
+  }
+};
