@@ -104,6 +104,7 @@ __device__ __forceinline__ uint3 dpp_from_lane_below(const uint3 &v) {
 }
 
 constexpr int kWalkCols = 63;
+constexpr int kWalkBatch = 8;  // rows whose gathers are issued together
 
 __global__ __launch_bounds__(256) void sample_rect_walk_kernel(
     uint8_t *__restrict__ dst, int out_w, int out_h, int out_stride_px,
@@ -118,43 +119,65 @@ __global__ __launch_bounds__(256) void sample_rect_walk_kernel(
   const int ic = min(max(i, 0), out_w - 1);
   const AxisBox bx = sample_axis(cxp, gx[ic + 1], gx[ic], src_w, true);
   const bool writes = lane > 0 && i < out_w && bx.ok;
+  // lane 0 never writes, so it never needs a left corner of its own
   const bool left_shared =
-      lane > 0 && dpp_from_lane_below((uint32_t)bx.hi) == (uint32_t)bx.lo;
+      lane == 0 || dpp_from_lane_below((uint32_t)bx.hi) == (uint32_t)bx.lo;
   const uint32_t dxw = (uint32_t)(bx.hi - bx.lo);
 
   const int j0 = blockIdx.y * rows, j1 = min(j0 + rows, out_h);
   int prev_hi = -1;
   uint3 p_br = make_uint3(0, 0, 0), p_bl = make_uint3(0, 0, 0);
-  for (int j = j0; j < j1; ++j) {
-    const AxisBox by = sample_axis(cyp, gy[j + 1], gy[j], src_h, false);  // wave-uniform
-    if (!by.ok) {
+  for (int jb = j0; jb < j1; jb += kWalkBatch) {
+    // wave-uniform row boxes of the batch, then all of its gathers at once
+    AxisBox by[kWalkBatch];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < kWalkBatch; ++r) {
+      const int j = min(jb + r, out_h - 1);
+      by[r] = sample_axis(cyp, gy[j + 1], gy[j], src_h, false);
+      by[r].ok = by[r].ok && (jb + r < j1);
+      any = any || by[r].ok;
+    }
+    if (!any) {
       prev_hi = -1;
       continue;
     }
-    const uint3 br = load_sat3(sat, (size_t)by.hi * src_w + bx.hi);
-    uint3 bl = dpp_from_lane_below(br);
-    if (!left_shared) bl = load_sat3(sat, (size_t)by.hi * src_w + bx.lo);
-    uint3 tr, tl;
-    if (by.lo == prev_hi) {
-      tr = p_br;
-      tl = p_bl;
-    } else {
-      tr = load_sat3(sat, (size_t)by.lo * src_w + bx.hi);
-      tl = dpp_from_lane_below(tr);
-      if (!left_shared) tl = load_sat3(sat, (size_t)by.lo * src_w + bx.lo);
+    uint3 brs[kWalkBatch];
+#pragma unroll
+    for (int r = 0; r < kWalkBatch; ++r)  // clamped corners are always in range
+      brs[r] = load_sat3(sat, (size_t)by[r].hi * src_w + bx.hi);
+#pragma unroll
+    for (int r = 0; r < kWalkBatch; ++r) {
+      if (!by[r].ok) {
+        prev_hi = -1;
+        continue;
+      }
+      const int j = jb + r;
+      const uint3 br = brs[r];
+      uint3 bl = dpp_from_lane_below(br);
+      if (!left_shared) bl = load_sat3(sat, (size_t)by[r].hi * src_w + bx.lo);
+      uint3 tr, tl;
+      if (by[r].lo == prev_hi) {
+        tr = p_br;
+        tl = p_bl;
+      } else {
+        tr = load_sat3(sat, (size_t)by[r].lo * src_w + bx.hi);
+        tl = dpp_from_lane_below(tr);
+        if (!left_shared) tl = load_sat3(sat, (size_t)by[r].lo * src_w + bx.lo);
+      }
+      if (writes) {
+        const uint32_t area = dxw * (uint32_t)(by[r].hi - by[r].lo);
+        uint8_t *o = dst + ((size_t)j * out_stride_px + i) * 4;
+        const uint32_t rr = udiv_exact(br.x - tr.x + tl.x - bl.x, area);
+        const uint32_t gg = udiv_exact(br.y - tr.y + tl.y - bl.y, area);
+        const uint32_t bb = udiv_exact(br.z - tr.z + tl.z - bl.z, area);
+        *reinterpret_cast<uint16_t *>(o) = (uint16_t)((rr & 0xffu) | ((gg & 0xffu) << 8));
+        o[2] = (uint8_t)bb;
+      }
+      p_br = br;
+      p_bl = bl;
+      prev_hi = by[r].hi;
     }
-    if (writes) {
-      const uint32_t area = dxw * (uint32_t)(by.hi - by.lo);
-      uint8_t *o = dst + ((size_t)j * out_stride_px + i) * 4;
-      const uint32_t r = udiv_exact(br.x - tr.x + tl.x - bl.x, area);
-      const uint32_t g = udiv_exact(br.y - tr.y + tl.y - bl.y, area);
-      const uint32_t b = udiv_exact(br.z - tr.z + tl.z - bl.z, area);
-      *reinterpret_cast<uint16_t *>(o) = (uint16_t)((r & 0xffu) | ((g & 0xffu) << 8));
-      o[2] = (uint8_t)b;
-    }
-    p_br = br;
-    p_bl = bl;
-    prev_hi = by.hi;
   }
 }
 

@@ -125,9 +125,84 @@ __device__ __forceinline__ void load12(const uint32_t *src, uint32_t (&a)[12]) {
 
 // ---- K1: column / row / tile sums ------------------------------------------
 // One workgroup (4 waves) per (strip, super-band).  Every band's rows are
-// split into four contiguous quarters, one per wave, so four times as many
-// loads are in flight as with one wave per tile; the waves' running column
-// sums meet in LDS once per band.
+// split into four contiguous quarters, one per wave; the waves' running column
+// sums meet in LDS once per band.  Rows are loaded in batches of kRowUnroll,
+// double-buffered (batch t+1 is in flight while batch t is summed).  Red and
+// blue travel together as two 16-bit fields of one register (x & 0x00ff00ff):
+// a quarter band is at most 16 rows, so neither a lane's column sums (<= 4080)
+// nor a strip's row sums (<= 65280) can carry from one field into the other.
+struct ReduceState {
+  uint32_t col[12];          // column sums of this wave's rows since the super-band began
+  uint32_t crb[4], cg[4];    // current band: packed R|B<<16 and green column sums
+  uint32_t tile[3];          // lane 63: strip sums of this wave's rows of the current band
+};
+
+template <bool VEC>
+__device__ __forceinline__ void reduce_load_batch(const EncodeArgs &a,
+                                                  uint4 (&raw)[kRowUnroll], int y,
+                                                  int y_hi, int x0) {
+#pragma unroll
+  for (int r = 0; r < kRowUnroll; ++r)
+    raw[r] = (y + r < y_hi)
+                 ? load_px4<VEC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
+                 : make_uint4(0, 0, 0, 0);
+}
+
+__device__ __forceinline__ void reduce_rows(const EncodeArgs &a, ReduceState &st,
+                                            const uint4 (&raw)[kRowUnroll], int y,
+                                            int y_hi, int strip, int lane) {
+#pragma unroll
+  for (int r = 0; r < kRowUnroll; r += 2) {
+    if (y + r >= y_hi) break;
+    uint32_t rb[2], g[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // rows beyond y_hi were loaded as zeros
+      const uint32_t v[4] = {raw[r + h].x, raw[r + h].y, raw[r + h].z, raw[r + h].w};
+      rb[h] = 0;
+      g[h] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t m = v[k] & 0x00ff00ffu;
+        const uint32_t gg = (v[k] >> 8) & 0xffu;
+        st.crb[k] += m;
+        st.cg[k] += gg;
+        rb[h] += m;
+        g[h] += gg;
+      }
+    }
+    // strip sums end up in lane 63; the two rows' greens share one scan
+    const uint32_t t0 = wave_scan_incl(rb[0]);
+    const uint32_t t1 = wave_scan_incl(rb[1]);
+    const uint32_t tg = wave_scan_incl(g[0] | (g[1] << 16));
+    if (lane == 63) {
+      uint32_t *rs = a.rowsum + ((size_t)strip * a.height + (y + r)) * 3;
+      rs[0] = t0 & 0xffffu;
+      rs[1] = tg & 0xffffu;
+      rs[2] = t0 >> 16;
+      if (y + r + 1 < y_hi) {
+        rs[3] = t1 & 0xffffu;
+        rs[4] = tg >> 16;
+        rs[5] = t1 >> 16;
+      }
+      st.tile[0] += (t0 & 0xffffu) + (t1 & 0xffffu);
+      st.tile[1] += (tg & 0xffffu) + (tg >> 16);
+      st.tile[2] += (t0 >> 16) + (t1 >> 16);
+    }
+  }
+}
+
+// fold the current band's packed sums into the 32-bit running sums
+__device__ __forceinline__ void reduce_flush_band(ReduceState &st) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    st.col[3 * k + 0] += st.crb[k] & 0xffffu;
+    st.col[3 * k + 1] += st.cg[k];
+    st.col[3 * k + 2] += st.crb[k] >> 16;
+    st.crb[k] = 0;
+    st.cg[k] = 0;
+  }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
     const EncodeArgs a) {
@@ -139,17 +214,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
   const int sb = blockIdx.y;
   const int x0 = strip * kStripPx + lane * kLanePx;
   const int quarter = a.band_rows / kWavesPerBlock;
+  const int per_band = (quarter + kRowUnroll - 1) / kRowUnroll;  // batches per band and wave
 
-  uint32_t col[12];  // this wave's rows only, since the start of the super-band
+  ReduceState st;
 #pragma unroll
-  for (int e = 0; e < 12; ++e) col[e] = 0;
+  for (int e = 0; e < 12; ++e) st.col[e] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) st.crb[k] = st.cg[k] = 0;
+  st.tile[0] = st.tile[1] = st.tile[2] = 0;
 
   const int band0 = sb * a.sb_bands;
   const int band_end = min(band0 + a.sb_bands, a.nbands);
-  // iteration `band_end` only publishes the super-band totals
-  for (int band = band0; band <= band_end; ++band) {
+  const int steps = (band_end - band0) * per_band;
+  // step t -> rows [y, y_hi) of this wave
+  auto rows_of = [&](int t, int &y, int &y_hi) {
+    const int band = band0 + t / per_band;
+    const int q_lo = band * a.band_rows + wave * quarter;
+    y = q_lo + (t % per_band) * kRowUnroll;
+    y_hi = (t < steps) ? min(min(q_lo + quarter, (band + 1) * a.band_rows), a.height) : 0;
+  };
+  // at a band's first step: publish this wave's running column sums, let one
+  // wave add the four and store the row of sums above the band
+  auto publish = [&](int band) {
     const int buf = (band - band0) & 1;
-    store12(&part[buf][wave][lane * 12], col);
+    store12(&part[buf][wave][lane * 12], st.col);
+    if (lane == 63) {
+      tpart[buf ^ 1][wave][0] = st.tile[0];  // totals of the band just finished
+      tpart[buf ^ 1][wave][1] = st.tile[1];
+      tpart[buf ^ 1][wave][2] = st.tile[2];
+    }
+    st.tile[0] = st.tile[1] = st.tile[2] = 0;
     __syncthreads();
     if (wave == ((band - band0) & 3)) {
       uint32_t sum[12], t[12];
@@ -164,55 +258,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
                                        : a.sbtotal + (size_t)sb * a.wp3) +
                       (size_t)x0 * 3;
       store12(dst, sum);
-      if (band > band0 && lane < 3) {  // previous band's tile total
-        const int pb = buf ^ 1;
+      if (band > band0 && lane < 3)
         a.tiletotal[((size_t)strip * a.nbands + (band - 1)) * 3 + lane] =
-            tpart[pb][0][lane] + tpart[pb][1][lane] + tpart[pb][2][lane] +
-            tpart[pb][3][lane];
-      }
+            tpart[buf ^ 1][0][lane] + tpart[buf ^ 1][1][lane] +
+            tpart[buf ^ 1][2][lane] + tpart[buf ^ 1][3][lane];
     }
-    if (band == band_end) break;
+  };
 
-    const int y_lo = band * a.band_rows + wave * quarter;
-    const int y_hi = min(min(y_lo + quarter, (band + 1) * a.band_rows), a.height);
-    uint32_t tile_r = 0, tile_g = 0, tile_b = 0;  // lane 63 only
-    for (int y = y_lo; y < y_hi; y += kRowUnroll) {
-      uint4 raw[kRowUnroll];
-#pragma unroll
-      for (int r = 0; r < kRowUnroll; ++r)
-        raw[r] = (y + r < y_hi)
-                     ? load_px4<VEC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
-                     : make_uint4(0, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < kRowUnroll; ++r) {
-        if (y + r >= y_hi) break;
-        uint32_t c[12];
-        unpack_px4(raw[r], c);
-#pragma unroll
-        for (int e = 0; e < 12; ++e) col[e] += c[e];
-        // strip sum of this row: R and G share one scan (each < 2^16)
-        const uint32_t sr = c[0] + c[3] + c[6] + c[9];
-        const uint32_t sg = c[1] + c[4] + c[7] + c[10];
-        const uint32_t sbl = c[2] + c[5] + c[8] + c[11];
-        const uint32_t inc_rg = wave_scan_incl(sr | (sg << 16));
-        const uint32_t inc_b = wave_scan_incl(sbl);
-        if (lane == 63) {
-          uint32_t *rs = a.rowsum + ((size_t)strip * a.height + (y + r)) * 3;
-          rs[0] = inc_rg & 0xffffu;
-          rs[1] = inc_rg >> 16;
-          rs[2] = inc_b;
-          tile_r += inc_rg & 0xffffu;
-          tile_g += inc_rg >> 16;
-          tile_b += inc_b;
-        }
-      }
-    }
-    if (lane == 63) {
-      tpart[buf][wave][0] = tile_r;
-      tpart[buf][wave][1] = tile_g;
-      tpart[buf][wave][2] = tile_b;
-    }
+  uint4 buf_a[kRowUnroll], buf_b[kRowUnroll];
+  int y, y_hi, ny, ny_hi;
+  rows_of(0, y, y_hi);
+  reduce_load_batch<VEC>(a, buf_a, y, y_hi, x0);
+  for (int t = 0; t < steps; t += 2) {
+    // even step: sum buf_a while buf_b loads
+    rows_of(t + 1, ny, ny_hi);
+    reduce_load_batch<VEC>(a, buf_b, ny, ny_hi, x0);
+    if (t % per_band == 0) publish(band0 + t / per_band);
+    reduce_rows(a, st, buf_a, y, y_hi, strip, lane);
+    if ((t + 1) % per_band == 0) reduce_flush_band(st);
+    if (t + 1 >= steps) break;
+    // odd step: sum buf_b while buf_a loads
+    rows_of(t + 2, y, y_hi);
+    reduce_load_batch<VEC>(a, buf_a, y, y_hi, x0);
+    if ((t + 1) % per_band == 0) publish(band0 + (t + 1) / per_band);
+    reduce_rows(a, st, buf_b, ny, ny_hi, strip, lane);
+    if ((t + 2) % per_band == 0) reduce_flush_band(st);
   }
+  publish(band_end);  // super-band totals and the last band's tile total
 }
 
 // ---- K2: exclusive prefixes of the carry arrays ------------------------------
@@ -227,21 +299,16 @@ __device__ __forceinline__ void carry_scan_segment(const ScanSeg &s, int blk) {
   const int i = blk * 256 + (int)threadIdx.x;
   if (i >= s.n) return;
   uint32_t run = 0;
-  int k = 0;
-  for (; k + 8 <= s.K; k += 8) {
-    uint32_t t[8];
+  for (int k = 0; k < s.K; k += 32) {  // 32 loads in flight per lane
+    uint32_t t[32];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t[q] = s.in[(size_t)(k + q) * s.n + i];
+    for (int q = 0; q < 32; ++q)
+      t[q] = (k + q < s.K) ? s.in[(size_t)(k + q) * s.n + i] : 0u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      s.out[(size_t)(k + q) * s.n + i] = run;
+    for (int q = 0; q < 32; ++q) {
+      if (k + q < s.K) s.out[(size_t)(k + q) * s.n + i] = run;
       run += t[q];
     }
-  }
-  for (; k < s.K; ++k) {
-    const uint32_t t = s.in[(size_t)k * s.n + i];
-    s.out[(size_t)k * s.n + i] = run;
-    run += t;
   }
 }
 
