@@ -168,10 +168,10 @@ def main():
         s.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the only collective: RCCL max of the timing
-        elapsed = float(t.item())
+    # the only collective of the run: RCCL max of the timing / sum of the pixels
+    from importlib import import_module
+    sharding = import_module("foveated-360-video_amd.sharding")
+    elapsed, total_px = sharding.reduce_run(elapsed, float(args.steps) * B * w * h, device=dev)
 
     # ---- per-kernel times of the sampled frames (HIP events on the launch stream) --------
     prof = {}
@@ -182,7 +182,6 @@ def main():
             a[1] += n
     kernels = {name: {"avg_us": round(1e3 * ms / n, 2), "launches": n} for name, (ms, n) in prof.items()}
 
-    total_px = float(world) * args.steps * B * w * h
     value = total_px / 1e6 / elapsed
     enc_bytes, smp_bytes = algorithmic_bytes(w, h, rw, rh)
 

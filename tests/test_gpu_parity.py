@@ -449,3 +449,30 @@ def test_error_behaviour(f360, gpu_ctx):
         cpu_only.EncodeFrameGPU(buf.ptr, buf.ptr, 8, 8, 32)
     assert e.value.status == f360.F360_ERR_NOT_INITIALIZED
     buf.free()
+
+
+# ------------------------------------------------- reference-style C++ caller (drop-in headers)
+def test_cpp_dropin_example(f360, gpu_ctx, oracle):
+    """examples/run_satlogrectilinear_synth.cc drives the engine through include/f360/*.h with
+    the reference's own call sequence; its digests must equal the oracle's."""
+    import json
+    import subprocess
+    repo = os.path.dirname(HERE)
+    exe = os.path.join(repo, "examples", "run_satlogrectilinear_synth")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(repo, "examples")], check=True)
+    w, h = 640, 320
+    rw, rh = reduced(w), reduced(h)
+    out = subprocess.run([exe, "foveate_no_encoding", str(w), str(h), "1"], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    frame = oracle.lcg_frame(w, h, 12345)
+    sat = oracle.sat_encode(frame, w, h, 4 * w)
+    red = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+    oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, oracle.satdec_grid(rw, rh, w, h),
+                              0.5, 0.5)
+    full = oracle.satdec_interpolate_rect(red, w, h, rw, rh, 0.5, 0.5)
+    assert got["sat"] == f"{oracle.fnv1a64(sat):016x}"
+    assert got["rect"] == f"{oracle.fnv1a64(red):016x}"
+    assert got["full"] == f"{oracle.fnv1a64(full):016x}"
