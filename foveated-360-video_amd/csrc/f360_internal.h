@@ -88,11 +88,13 @@ struct f360_ctx {
   bool owns_stream = false;
   f360::SatEncodePlan enc;
   // options (f360_ctx_set_option)
-  int opt_band_rows = 32;      // "sat.band_rows": 16 | 32 | 64
-  int opt_sb_bands = 8;        // "sat.sb_bands"
+  int opt_band_rows = 64;      // "sat.band_rows": 16 | 32 | 64
+  int opt_sb_bands = 2;        // "sat.sb_bands": bands per reducer wave
   int opt_store_mode = 1;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-staged contiguous stores
-  int opt_sample_variant = 0;  // "sample.variant": 0 per-pixel, 1 column walker
-  int opt_walk_rows = 32;      // "sample.rows": reduced rows per wave of the column walker
+  int opt_sample_variant = 1;  // "sample.variant": 0 per-pixel, 1 column walker, 2 row streaming, 3 hybrid
+  int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker
+  int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
+  int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;
@@ -153,6 +155,12 @@ struct f360_sat_decoder {
   int gw = 0, gh = 0, sw = 0, sh = 0;  // target / source geometry of the grid
   std::vector<int16_t> gx_host, gy_host;  // gw+1 / gh+1 entries
   f360::DevBuf gx_dev, gy_dev;
+  // row-streaming sampler: inverse of the x grid, largest corner step (+1, rounded to 4)
+  f360::DevBuf lbx_dev;
+  int lb_dmin = 0, lb_n = 0, halo = 0;
+  bool stream_ok = false;
+  int dense_begin = 0, dense_end = 0;  // reduced columns with unit corner steps (fovea)
+  int hybrid_passes = 0;               // 0: hybrid sampler not applicable
   // inverse-map tables of the interpolate kernel, indexed by pixel offset from
   // the gaze centre (geometry-only; see sat_decoder.hip)
   int it_w = 0, it_h = 0, it_rw = 0, it_rh = 0;  // geometry they were built for

@@ -244,6 +244,8 @@ static const OptionSlot kOptions[] = {
     {"sat.reverse", &f360_ctx::opt_reverse_tiles},
     {"sample.variant", &f360_ctx::opt_sample_variant},
     {"sample.rows", &f360_ctx::opt_walk_rows},
+    {"debug.ablate", &f360_ctx::opt_ablate},
+    {"sample.reverse", &f360_ctx::opt_sample_reverse},
 };
 
 int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {

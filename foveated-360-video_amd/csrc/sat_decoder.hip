@@ -10,6 +10,7 @@
 // separable (x depends on the column only, y on the row only); they live in
 // 1-D tables built on the host (host_tables.cpp) so the kernels below are pure
 // integer / IEEE-float gather kernels.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -62,6 +63,35 @@ __device__ __forceinline__ uint32_t udiv_exact(uint32_t n, uint32_t d) {
   return n / d;
 }
 
+// The three channel quotients of one box, exact.  Common case (all operands
+// < 2^22): ONE hardware reciprocal (1 ulp) shared by the channels, a float
+// multiply per channel -- off by at most one, since n/d < 2^22 and the relative
+// error is < 2^-22 -- then the exact remainder decides the +-1 correction.
+__device__ __noinline__ uint3 udiv3_slow(uint3 n, uint32_t d) {
+  return make_uint3(n.x / d, n.y / d, n.z / d);
+}
+__device__ __forceinline__ uint32_t udiv_by_rcp(uint32_t n, float inv, uint32_t d) {
+  uint32_t q = (uint32_t)((float)n * inv);
+  const uint32_t r = n - __umul24(q, d);
+  if ((int32_t)r < 0) q -= 1;
+  else if (r >= d) q += 1;
+  return q;
+}
+__device__ __forceinline__ uint3 udiv3_exact(uint3 n, uint32_t d) {
+  if (((n.x | n.y | n.z | d) >> 22) != 0) return udiv3_slow(n, d);
+  const float inv = __builtin_amdgcn_rcpf((float)d);
+  return make_uint3(udiv_by_rcp(n.x, inv, d), udiv_by_rcp(n.y, inv, d),
+                    udiv_by_rcp(n.z, inv, d));
+}
+
+// 12-byte texel at a 32-bit BYTE offset from the table base (the table is < 4 GiB on
+// this path): scalar base + 32-bit vector offset addressing, no 64-bit arithmetic
+__device__ __forceinline__ uint3 load_sat3_at(const uint32_t *sat, uint32_t byte_off) {
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(
+      reinterpret_cast<const char *>(sat) + byte_off);
+  return make_uint3(p[0], p[1], p[2]);
+}
+
 // Variant 0: one thread per reduced pixel.
 __global__ __launch_bounds__(256) void sample_rect_kernel(
     uint8_t *__restrict__ dst, int out_w, int out_h, int out_stride_px,
@@ -106,25 +136,45 @@ __device__ __forceinline__ uint3 dpp_from_lane_below(const uint3 &v) {
 constexpr int kWalkCols = 63;
 constexpr int kWalkBatch = 8;  // rows whose gathers are issued together
 
-__global__ __launch_bounds__(256) void sample_rect_walk_kernel(
-    uint8_t *__restrict__ dst, int out_w, int out_h, int out_stride_px,
-    const uint32_t *__restrict__ sat, int src_w, int src_h,
-    const int16_t *__restrict__ gx, const int16_t *__restrict__ gy, int cxp,
-    int cyp, int rows) {
+struct SampleArgs {
+  uint8_t *dst;
+  int out_w, out_h, out_stride_px;
+  const uint32_t *sat;
+  int src_w, src_h;
+  const int16_t *gx, *gy;
+  int cxp, cyp;
+  // row-streaming / hybrid
+  const int *lbx;
+  int lb_dmin, lb_n, halo;
+  int dense_begin, dense_end;  // reduced columns [begin, end) with unit steps (the fovea)
+  int walk_blocks;             // hybrid: blockIdx.x below this runs the walker
+  int ablate;                  // timing experiments only
+  int reverse;                 // visit the row runs bottom-up (the table's last rows are the
+                               // most recently written, hence the likeliest to be cached)
+};
+
+__device__ __forceinline__ void store_rgb(uint8_t *o, uint32_t r, uint32_t g, uint32_t b) {
+  *reinterpret_cast<uint16_t *>(o) = (uint16_t)((r & 0xffu) | ((g & 0xffu) << 8));
+  o[2] = (uint8_t)b;
+}
+
+// One wave: reduced columns [c0, c0 + 63) clipped to [col_begin, col_end), rows [j0, j1).
+__device__ __forceinline__ void walk_body(const SampleArgs &a, int c0, int col_begin,
+                                          int col_end, int j0, int j1) {
   const int lane = threadIdx.x & 63;
-  const int c0 = __builtin_amdgcn_readfirstlane(
-      ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kWalkCols);
-  if (c0 >= out_w) return;  // whole wave
   const int i = c0 - 1 + lane;
-  const int ic = min(max(i, 0), out_w - 1);
-  const AxisBox bx = sample_axis(cxp, gx[ic + 1], gx[ic], src_w, true);
-  const bool writes = lane > 0 && i < out_w && bx.ok;
+  const int ic = min(max(i, 0), a.out_w - 1);
+  const AxisBox bx = sample_axis(a.cxp, a.gx[ic + 1], a.gx[ic], a.src_w, true);
+  const bool writes = lane > 0 && i >= col_begin && i < col_end && bx.ok;
   // lane 0 never writes, so it never needs a left corner of its own
   const bool left_shared =
       lane == 0 || dpp_from_lane_below((uint32_t)bx.hi) == (uint32_t)bx.lo;
   const uint32_t dxw = (uint32_t)(bx.hi - bx.lo);
+  const uint32_t *sat = a.sat;
+  const uint32_t row_bytes = (uint32_t)a.src_w * 12u;
+  const uint32_t x_hi = (uint32_t)bx.hi * 12u, x_lo = (uint32_t)bx.lo * 12u;
+  uint8_t *out = a.dst + (size_t)i * 4;
 
-  const int j0 = blockIdx.y * rows, j1 = min(j0 + rows, out_h);
   int prev_hi = -1;
   uint3 p_br = make_uint3(0, 0, 0), p_bl = make_uint3(0, 0, 0);
   for (int jb = j0; jb < j1; jb += kWalkBatch) {
@@ -133,8 +183,8 @@ __global__ __launch_bounds__(256) void sample_rect_walk_kernel(
     bool any = false;
 #pragma unroll
     for (int r = 0; r < kWalkBatch; ++r) {
-      const int j = min(jb + r, out_h - 1);
-      by[r] = sample_axis(cyp, gy[j + 1], gy[j], src_h, false);
+      const int j = min(jb + r, a.out_h - 1);
+      by[r] = sample_axis(a.cyp, a.gy[j + 1], a.gy[j], a.src_h, false);
       by[r].ok = by[r].ok && (jb + r < j1);
       any = any || by[r].ok;
     }
@@ -145,40 +195,262 @@ __global__ __launch_bounds__(256) void sample_rect_walk_kernel(
     uint3 brs[kWalkBatch];
 #pragma unroll
     for (int r = 0; r < kWalkBatch; ++r)  // clamped corners are always in range
-      brs[r] = load_sat3(sat, (size_t)by[r].hi * src_w + bx.hi);
+      brs[r] = load_sat3_at(sat, (uint32_t)by[r].hi * row_bytes + x_hi);
 #pragma unroll
     for (int r = 0; r < kWalkBatch; ++r) {
       if (!by[r].ok) {
         prev_hi = -1;
         continue;
       }
-      const int j = jb + r;
       const uint3 br = brs[r];
       uint3 bl = dpp_from_lane_below(br);
-      if (!left_shared) bl = load_sat3(sat, (size_t)by[r].hi * src_w + bx.lo);
+      if (!left_shared) bl = load_sat3_at(sat, (uint32_t)by[r].hi * row_bytes + x_lo);
       uint3 tr, tl;
       if (by[r].lo == prev_hi) {
         tr = p_br;
         tl = p_bl;
       } else {
-        tr = load_sat3(sat, (size_t)by[r].lo * src_w + bx.hi);
+        tr = load_sat3_at(sat, (uint32_t)by[r].lo * row_bytes + x_hi);
         tl = dpp_from_lane_below(tr);
-        if (!left_shared) tl = load_sat3(sat, (size_t)by[r].lo * src_w + bx.lo);
+        if (!left_shared) tl = load_sat3_at(sat, (uint32_t)by[r].lo * row_bytes + x_lo);
       }
       if (writes) {
-        const uint32_t area = dxw * (uint32_t)(by[r].hi - by[r].lo);
-        uint8_t *o = dst + ((size_t)j * out_stride_px + i) * 4;
-        const uint32_t rr = udiv_exact(br.x - tr.x + tl.x - bl.x, area);
-        const uint32_t gg = udiv_exact(br.y - tr.y + tl.y - bl.y, area);
-        const uint32_t bb = udiv_exact(br.z - tr.z + tl.z - bl.z, area);
-        *reinterpret_cast<uint16_t *>(o) = (uint16_t)((rr & 0xffu) | ((gg & 0xffu) << 8));
-        o[2] = (uint8_t)bb;
+        const uint3 q = udiv3_exact(make_uint3(br.x - tr.x + tl.x - bl.x, br.y - tr.y + tl.y - bl.y,
+                                               br.z - tr.z + tl.z - bl.z),
+                                    dxw * (uint32_t)(by[r].hi - by[r].lo));
+        store_rgb(out + (size_t)(jb + r) * ((size_t)a.out_stride_px * 4), q.x, q.y, q.z);
       }
       p_br = br;
       p_bl = bl;
       prev_hi = by[r].hi;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void sample_rect_walk_kernel(const SampleArgs a, int rows) {
+  const int c0 = __builtin_amdgcn_readfirstlane(
+      ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kWalkCols);
+  if (c0 >= a.out_w) return;  // whole wave
+  const int by = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int j0 = by * rows;
+  walk_body(a, c0, 0, a.out_w, j0, min(j0 + rows, a.out_h));
+}
+
+// Variant 2 ("row streaming").  At 8K a gaze touches ~1900 table rows and every
+// 128-byte line of each of them, yet a gather uses 12 bytes of each 64-byte
+// request in the periphery.  Here a wave owns a 256-texel source tile and a run
+// of reduced rows: it streams the tile's segment of every table row the run
+// needs with coalesced 16-byte loads into wave-private LDS, and the lanes pick
+// their corners from LDS.  A reduced pixel belongs to the tile that contains
+// its (wrapped, clamped) right corner, so every pixel is produced exactly once;
+// its left corner lies at most `halo` texels to the left, inside the segment
+// (a corner that is not is fetched from memory, so the result is the
+// reference's regardless).  The candidate pixels of a tile come from a
+// host-built inverse of the x grid: lbx[d] = first grid index with offset >= d.
+// Variant 3 ("hybrid") gives the fovea's unit-step columns, where gathers are
+// already contiguous, to the walker and streams only the periphery.
+constexpr int kTileTexels = 256;
+constexpr int kMaxHalo = 64;
+constexpr int kStreamRows = 8;  // reduced rows per wave
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// Wave-private LDS exchange goes through inline asm: the compiler's memory
+// model is per lane and it deletes plain LDS stores that only OTHER lanes read.
+// One wave's LDS operations execute in order, so no barrier is needed.
+__device__ __forceinline__ void lds_store16(uint32_t addr, u32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_store4(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_load4(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+// two 12-byte texels (4-byte aligned) with one wait
+__device__ __forceinline__ void lds_load_texels(uint32_t addr_a, uint32_t addr_b, uint3 &a,
+                                                uint3 &b) {
+  u32x2_t a01, b01;
+  uint32_t a2, b2;
+  asm volatile(
+      "ds_read2_b32 %0, %4 offset1:1\n\t"
+      "ds_read_b32 %1, %4 offset:8\n\t"
+      "ds_read2_b32 %2, %5 offset1:1\n\t"
+      "ds_read_b32 %3, %5 offset:8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a01), "=&v"(a2), "=&v"(b01), "=&v"(b2)
+      : "v"(addr_a), "v"(addr_b)
+      : "memory");
+  a = make_uint3(a01.x, a01.y, a2);
+  b = make_uint3(b01.x, b01.y, b2);
+}
+
+constexpr int kStageDwords = (kTileTexels + kMaxHalo) * 3 + 2 * kStreamRows + 4;
+
+// One wave: source tile `tile`, reduced rows [j0, j0 + kStreamRows); reduced columns in
+// [a.dense_begin, a.dense_end) are somebody else's.  `lds0` is this wave's LDS region.
+template <int PASSES>
+__device__ __forceinline__ void stream_body(const SampleArgs &a, int tile, int j0,
+                                            uint32_t lds0) {
+  const int lane = threadIdx.x & 63;
+  const int src_w = a.src_w;
+  const int ntiles = (src_w + kTileTexels - 1) / kTileTexels;
+  const uint32_t lds_sched = lds0 + (kTileTexels + kMaxHalo) * 12;
+
+  // ---- the tile's segment of a table row
+  const int x_tile = tile * kTileTexels;
+  const int seg_x0 = max(x_tile - a.halo, 0);
+  const int seg_x1 = min(x_tile + kTileTexels, src_w);
+  const int seg_vec = (seg_x1 - seg_x0) * 3 / 4;  // 16-byte vectors; width % 4 == 0
+
+  // ---- candidate pixels: wrap states k = 0, +1, -1; each a contiguous column range, cut
+  // in two by the excluded dense range
+  int cnt[6], first[6];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int k = q == 0 ? 0 : (q == 1 ? 1 : -1);
+    // unwrapped right corner cxp + gx[i+1] in [lo_b, hi_b); the last tile also takes the
+    // pixels that straddle the seam (their corner is clamped back to src_w - 1)
+    const int lo_b = x_tile + k * src_w - a.cxp;
+    const int hi_b = lo_b + kTileTexels + (tile == ntiles - 1 ? a.halo : 0);
+    const int g_lo = a.lbx[min(max(lo_b - a.lb_dmin, 0), a.lb_n - 1)];
+    const int g_hi = a.lbx[min(max(hi_b - a.lb_dmin, 0), a.lb_n - 1)];
+    const int i_lo = max(g_lo - 1, 0);  // grid index g is the right corner of pixel g - 1
+    const int i_hi = max(min(g_hi - 1, a.out_w), i_lo);
+    first[2 * q] = i_lo;
+    cnt[2 * q] = max(min(i_hi, a.dense_begin) - i_lo, 0);
+    first[2 * q + 1] = max(i_lo, a.dense_end);
+    cnt[2 * q + 1] = max(i_hi - first[2 * q + 1], 0);
+  }
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) total += cnt[q];
+  if (total == 0) return;
+  const int npass = (total + 63) / 64;  // the host guarantees <= PASSES
+
+  // ---- schedule (in LDS, it is indexed dynamically): the table rows to stream.
+  // entry = row | box height << 16 | (reduced row - j0 + 1) << 24, the last field
+  // 0 for a row that only provides the top corners of the next box
+  int nsched = 0;
+  {
+    int prev = -1;
+    for (int r = 0; r < kStreamRows; ++r) {
+      const int j = j0 + r;
+      if (j >= a.out_h) break;
+      const AxisBox by = sample_axis(a.cyp, a.gy[j + 1], a.gy[j], a.src_h, false);
+      if (!by.ok) continue;
+      if (by.lo != prev) {
+        if (lane == 0) lds_store4(lds_sched + 4 * nsched, (uint32_t)by.lo);
+        ++nsched;
+      }
+      if (lane == 0)
+        lds_store4(lds_sched + 4 * nsched, (uint32_t)by.hi | ((uint32_t)(by.hi - by.lo) << 16) |
+                                               ((uint32_t)(r + 1) << 24));
+      ++nsched;
+      prev = by.hi;
+    }
+  }
+  if (nsched == 0) return;
+
+  int pi[PASSES];                        // reduced column, -1: no pixel
+  uint32_t off_hi[PASSES], off_lo[PASSES], dxw[PASSES];
+  int lo_x[PASSES];                      // >= 0: left corner lies outside the segment
+  uint3 p_hi[PASSES], p_lo[PASSES];      // corners of the previous streamed row
+  bool any_mine = false;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    pi[p] = -1;
+    off_hi[p] = off_lo[p] = 0;
+    dxw[p] = 1;
+    lo_x[p] = -1;
+    p_hi[p] = p_lo[p] = make_uint3(0, 0, 0);
+    if (p < npass) {
+      int q = p * 64 + lane;
+      int i = -1;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        if (i < 0 && q >= 0 && q < cnt[s]) i = first[s] + q;
+        q -= cnt[s];
+      }
+      if (i >= 0) {
+        const AxisBox bx = sample_axis(a.cxp, a.gx[i + 1], a.gx[i], src_w, true);
+        if (bx.ok && bx.hi >= x_tile && bx.hi < x_tile + kTileTexels) {
+          pi[p] = i;
+          off_hi[p] = (uint32_t)(bx.hi - seg_x0) * 12u;
+          dxw[p] = (uint32_t)(bx.hi - bx.lo);
+          if (bx.lo >= seg_x0) off_lo[p] = (uint32_t)(bx.lo - seg_x0) * 12u;
+          else lo_x[p] = bx.lo;
+          any_mine = true;
+        }
+      }
+    }
+  }
+  if (!__any(any_mine)) return;
+
+  // ---- stream: row n+1 travels from memory while row n is consumed from LDS
+  u32x4_t regs[4];
+  auto issue_loads = [&](int y) {
+    const u32x4_t *row =
+        reinterpret_cast<const u32x4_t *>(a.sat + ((size_t)y * src_w + seg_x0) * 3);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) regs[v] = row[min(v * 64 + lane, seg_vec - 1)];
+  };
+  uint32_t entry = __builtin_amdgcn_readfirstlane(lds_load4(lds_sched));
+  issue_loads((int)(entry & 0xffffu));
+  for (int n = 0; n < nsched; ++n) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (v * 64 + lane < seg_vec) lds_store16(lds0 + (uint32_t)(v * 64 + lane) * 16u, regs[v]);
+    const uint32_t cur = entry;
+    if (n + 1 < nsched) {
+      entry = __builtin_amdgcn_readfirstlane(lds_load4(lds_sched + 4 * (n + 1)));
+      issue_loads((int)(entry & 0xffffu));
+    }
+    const int y = (int)(cur & 0xffffu);
+    const uint32_t dy = (cur >> 16) & 0xffu;
+    const int rsel = (int)(cur >> 24);  // 0: top corners only
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      if (p >= npass) break;
+      uint3 hi, lo;
+      lds_load_texels(lds0 + off_hi[p], lds0 + off_lo[p], hi, lo);
+      if (lo_x[p] >= 0) lo = load_sat3(a.sat, (size_t)y * src_w + lo_x[p]);
+      if (rsel != 0 && pi[p] >= 0) {
+        const uint3 q = udiv3_exact(
+            make_uint3(hi.x - p_hi[p].x + p_lo[p].x - lo.x, hi.y - p_hi[p].y + p_lo[p].y - lo.y,
+                       hi.z - p_hi[p].z + p_lo[p].z - lo.z),
+            dxw[p] * dy);
+        store_rgb(a.dst + ((size_t)(j0 + rsel - 1) * a.out_stride_px + pi[p]) * 4, q.x, q.y,
+                  q.z);
+      }
+      p_hi[p] = hi;
+      p_lo[p] = lo;
+    }
+  }
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t stage[4][kStageDwords];
+  const int wave = threadIdx.x >> 6;
+  const int by = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int j0 = by * kStreamRows;
+  if ((int)blockIdx.x < a.walk_blocks) {  // hybrid only: the fovea's columns by gathers
+    if (a.ablate & 4) return;
+    const int c0 = __builtin_amdgcn_readfirstlane(a.dense_begin +
+                                                  ((int)blockIdx.x * 4 + wave) * kWalkCols);
+    if (c0 >= a.dense_end) return;
+    walk_body(a, c0, a.dense_begin, a.dense_end, j0, min(j0 + kStreamRows, a.out_h));
+    return;
+  }
+  if (a.ablate & 8) return;
+  const int tile =
+      __builtin_amdgcn_readfirstlane(((int)blockIdx.x - a.walk_blocks) * 4 + wave);
+  if (tile >= (a.src_w + kTileTexels - 1) / kTileTexels) return;
+  stream_body<PASSES>(a, tile, j0, (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]));
 }
 
 // ---------------------------------------------------------------------------
@@ -334,6 +606,7 @@ int f360_satdec_destroy(f360_sat_decoder *dec) {
   dec->gy_dev.release();
   dec->itx_dev.release();
   dec->ity_dev.release();
+  dec->lbx_dev.release();
   delete dec;
   return F360_OK;
 }
@@ -358,6 +631,69 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
   st = upload(dec->ctx, dec->gy_dev, dec->gy_host.data(),
               dec->gy_host.size() * sizeof(int16_t));
   if (st != F360_OK) return st;
+  // inverse of the x grid for the row-streaming sampler: lbx[d - dmin] = first grid
+  // index whose offset is >= d; plus the largest step between neighbouring corners
+  {
+    const std::vector<int16_t> &g = dec->gx_host;
+    const int dmin = g.front(), dmax = g.back() + 1;
+    std::vector<int> lb((size_t)(dmax - dmin + 1));
+    size_t gi = 0;
+    int max_step = 1, max_per_tile = 0;
+    for (int d = dmin; d <= dmax; ++d) {
+      while (gi < g.size() && g[gi] < d) ++gi;
+      lb[(size_t)(d - dmin)] = (int)gi;
+    }
+    for (size_t k = 1; k < g.size(); ++k) max_step = std::max(max_step, g[k] - g[k - 1]);
+    int max_step_y = 1;
+    for (size_t k = 1; k < dec->gy_host.size(); ++k)
+      max_step_y = std::max(max_step_y, dec->gy_host[k] - dec->gy_host[k - 1]);
+    dec->halo = (max_step + 1 + 3) & ~3;
+    dec->lb_dmin = dmin;
+    dec->lb_n = (int)lb.size();
+    // worst case over every gaze of the candidates one tile can receive from the three
+    // wrap states: grid points in [d, d + tile + halo) for d, d + W and d - W
+    auto lb_at = [&](long d) -> int {
+      if (d <= dmin) return 0;
+      if (d >= dmax) return (int)g.size();
+      return lb[(size_t)(d - dmin)];
+    };
+    const long win = kTileTexels + dec->halo;
+    for (long d = (long)dmin - source_width - win; d <= (long)dmax + source_width; ++d) {
+      int c = 0;
+      for (long k = -1; k <= 1; ++k)
+        c += lb_at(d + k * source_width + win) - lb_at(d + k * source_width);
+      max_per_tile = std::max(max_per_tile, c);
+    }
+    dec->stream_ok = dec->halo <= kMaxHalo && max_step_y < 256 && max_per_tile <= 64 * 6;
+    // the fovea: the longest run of reduced columns whose corners advance by one texel
+    {
+      int best_a = 0, best_b = 0, run_a = 0;
+      for (int i = 0; i <= target_width; ++i) {
+        const bool unit = i < target_width && g[(size_t)i + 1] - g[(size_t)i] == 1;
+        if (!unit) {
+          if (i - run_a > best_b - best_a) { best_a = run_a; best_b = i; }
+          run_a = i + 1;
+        }
+      }
+      dec->dense_begin = best_a;
+      dec->dense_end = best_b;
+      // worst-case candidates per tile once the fovea's columns are excluded
+      int worst = 0;
+      for (long d = (long)dmin - source_width - win; d <= (long)dmax + source_width; ++d) {
+        int c = 0;
+        for (long k = -1; k <= 1; ++k) {
+          const int ga = lb_at(d + k * source_width), gb = lb_at(d + k * source_width + win);
+          const int ia = std::max(ga - 1, 0), ib = std::max(std::min(gb - 1, target_width), ia);
+          c += std::max(std::min(ib, best_a) - ia, 0) + std::max(ib - std::max(ia, best_b), 0);
+        }
+        worst = std::max(worst, c);
+      }
+      dec->hybrid_passes = (best_b - best_a >= 256 && worst <= 64 * 6) ? (worst + 63) / 64 : 0;
+      if (dec->hybrid_passes == 0 && best_b - best_a >= 256 && worst <= 64 * 6) dec->hybrid_passes = 1;
+    }
+    st = upload(dec->ctx, dec->lbx_dev, lb.data(), lb.size() * sizeof(int));
+    if (st != F360_OK) return st;
+  }
   dec->gw = target_width;
   dec->gh = target_height;
   dec->sw = source_width;
@@ -412,24 +748,60 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   const int cxp = (int)(center_x * (float)source_width);
   const int cyp = (int)(center_y * (float)source_height);
   f360_ctx *ctx = dec->ctx;
-  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
-  if (ctx->opt_sample_variant == 1) {
+  SampleArgs sa;
+  sa.dst = target_dev;
+  sa.out_w = target_width;
+  sa.out_h = target_height;
+  sa.out_stride_px = target_linesize / 4;
+  sa.sat = sat_dev;
+  sa.src_w = source_width;
+  sa.src_h = source_height;
+  sa.gx = dec->gx_dev.as<int16_t>();
+  sa.gy = dec->gy_dev.as<int16_t>();
+  sa.cxp = cxp;
+  sa.cyp = cyp;
+  sa.lbx = dec->lbx_dev.as<int>();
+  sa.lb_dmin = dec->lb_dmin;
+  sa.lb_n = dec->lb_n;
+  sa.halo = dec->halo;
+  sa.dense_begin = sa.dense_end = 0;
+  sa.walk_blocks = 0;
+  sa.ablate = ctx->opt_ablate;
+  sa.reverse = ctx->opt_sample_reverse;
+  const int variant = ctx->opt_sample_variant;
+  const bool can_stream = dec->stream_ok && (source_width % 4) == 0 &&
+                          (size_t)source_width * source_height * 12 < ((size_t)1 << 32) &&
+                          ((uintptr_t)sat_dev % 16) == 0 && source_height <= 0xffff &&
+                          target_height < 0xffff;
+  const int tile_blocks = ((source_width + kTileTexels - 1) / kTileTexels + 3) / 4;
+  const int run_blocks = (target_height + kStreamRows - 1) / kStreamRows;
+  f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
+  if (variant == 3 && can_stream && dec->hybrid_passes > 0) {
+    sa.dense_begin = dec->dense_begin;
+    sa.dense_end = dec->dense_end;
+    sa.walk_blocks =
+        ((dec->dense_end - dec->dense_begin + kWalkCols - 1) / kWalkCols + 3) / 4;
+    const dim3 hgrid(sa.walk_blocks + tile_blocks, run_blocks);
+    if (dec->hybrid_passes <= 2)
+      hipLaunchKernelGGL(sample_rect_stream_kernel<2>, hgrid, dim3(256), 0, ctx->stream, sa);
+    else if (dec->hybrid_passes <= 3)
+      hipLaunchKernelGGL(sample_rect_stream_kernel<3>, hgrid, dim3(256), 0, ctx->stream, sa);
+    else
+      hipLaunchKernelGGL(sample_rect_stream_kernel<6>, hgrid, dim3(256), 0, ctx->stream, sa);
+  } else if (variant == 2 && can_stream) {
+    hipLaunchKernelGGL(sample_rect_stream_kernel<6>, dim3(tile_blocks, run_blocks), dim3(256),
+                       0, ctx->stream, sa);
+  } else if (variant >= 1 && (size_t)source_width * source_height * 12 < ((size_t)1 << 32)) {
     const int rows = ctx->opt_walk_rows;
     const dim3 wgrid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),
                      (target_height + rows - 1) / rows);
-    f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
-    hipLaunchKernelGGL(sample_rect_walk_kernel, wgrid, dim3(256), 0, ctx->stream,
-                       target_dev, target_width, target_height,
-                       target_linesize / 4, sat_dev, source_width, source_height,
-                       dec->gx_dev.as<int16_t>(), dec->gy_dev.as<int16_t>(), cxp,
-                       cyp, rows);
+    hipLaunchKernelGGL(sample_rect_walk_kernel, wgrid, dim3(256), 0, ctx->stream, sa, rows);
   } else {
-    f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
-    hipLaunchKernelGGL(sample_rect_kernel, grid, dim3(256), 0, ctx->stream,
-                       target_dev, target_width, target_height,
-                       target_linesize / 4, sat_dev, source_width, source_height,
-                       dec->gx_dev.as<int16_t>(), dec->gy_dev.as<int16_t>(), cxp,
-                       cyp);
+    const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+    hipLaunchKernelGGL(sample_rect_kernel, grid, dim3(256), 0, ctx->stream, target_dev,
+                       target_width, target_height, target_linesize / 4, sat_dev,
+                       source_width, source_height, dec->gx_dev.as<int16_t>(),
+                       dec->gy_dev.as<int16_t>(), cxp, cyp);
   }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;

@@ -74,6 +74,7 @@ struct EncodeArgs {
   int band_rows, sb_bands, nstrips, nbands, nsb, wp3;
   uint32_t *lp, *sbtotal, *sbprefix, *rowsum, *rowcarry, *tiletotal, *tprefix;
   int reverse;
+  int ablate;  // timing experiments only (results are wrong when non-zero)
 };
 
 // Four pixels of one row as packed R | G<<8 | B<<16 dwords (0 beyond the row).
@@ -124,46 +125,61 @@ __device__ __forceinline__ void load12(const uint32_t *src, uint32_t (&a)[12]) {
 }
 
 // ---- K1: column / row / tile sums ------------------------------------------
-// One workgroup (4 waves) per (strip, super-band).  Every band's rows are
-// split into four contiguous quarters, one per wave; the waves' running column
-// sums meet in LDS once per band.  Rows are loaded in batches of kRowUnroll,
-// double-buffered (batch t+1 is in flight while batch t is summed).  Red and
-// blue travel together as two 16-bit fields of one register (x & 0x00ff00ff):
-// a quarter band is at most 16 rows, so neither a lane's column sums (<= 4080)
-// nor a strip's row sums (<= 65280) can carry from one field into the other.
+// One wave per (strip, super-band), no workgroup synchronisation (a
+// __syncthreads() would drain the loads that are kept in flight).  A
+// super-band is a contiguous run of rows; they are loaded in batches of
+// kRowUnroll, double-buffered, without any per-row branch: addresses are
+// clamped into the frame and rows past the end are masked to zero (the masks
+// are wave-uniform, i.e. scalar registers).  Lanes past the right edge exist
+// only in the last strip, where nothing to their right consumes their sums, so
+// they need no mask at all.  Red and blue travel together as two 16-bit fields
+// (x & 0x00ff00ff), green as x & 0xff00: within one band (<= 64 rows) a lane's
+// column sums and a strip's row sums cannot carry from one field into the next.
 struct ReduceState {
-  uint32_t col[12];          // column sums of this wave's rows since the super-band began
-  uint32_t crb[4], cg[4];    // current band: packed R|B<<16 and green column sums
-  uint32_t tile[3];          // lane 63: strip sums of this wave's rows of the current band
+  uint32_t col[12];        // column sums of the rows since the super-band began
+  uint32_t crb[4], cg[4];  // current band: packed R|B<<16 and G<<8 column sums
+  uint32_t tile[3];        // lane 63: strip sums of the rows of the current band
 };
 
 template <bool VEC>
 __device__ __forceinline__ void reduce_load_batch(const EncodeArgs &a,
                                                   uint4 (&raw)[kRowUnroll], int y,
-                                                  int y_hi, int x0) {
+                                                  int x0) {
+  if (VEC) {
+    // branch-free: clamp into the frame, validity is applied by the caller's masks
+    const int xc = min(x0, a.width - kLanePx);
+    const uint8_t *p = a.src + (size_t)xc * 4;
 #pragma unroll
-  for (int r = 0; r < kRowUnroll; ++r)
-    raw[r] = (y + r < y_hi)
-                 ? load_px4<VEC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
-                 : make_uint4(0, 0, 0, 0);
+    for (int r = 0; r < kRowUnroll; ++r)
+      raw[r] = *reinterpret_cast<const uint4 *>(p + (size_t)min(y + r, a.height - 1) *
+                                                        a.linesize);
+  } else {
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r)
+      raw[r] = (y + r < a.height)
+                   ? load_px4<false>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
+                   : make_uint4(0, 0, 0, 0);
+  }
 }
 
+// sums rows [y, y + kRowUnroll) that lie below y_stop
 __device__ __forceinline__ void reduce_rows(const EncodeArgs &a, ReduceState &st,
                                             const uint4 (&raw)[kRowUnroll], int y,
-                                            int y_hi, int strip, int lane) {
+                                            int y_stop, int strip, int lane) {
 #pragma unroll
   for (int r = 0; r < kRowUnroll; r += 2) {
-    if (y + r >= y_hi) break;
     uint32_t rb[2], g[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // rows beyond y_hi were loaded as zeros
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t live = (y + r + h < y_stop) ? 0xffffffffu : 0u;  // scalar
+      const uint32_t mrb = 0x00ff00ffu & live, mg = 0x0000ff00u & live;
       const uint32_t v[4] = {raw[r + h].x, raw[r + h].y, raw[r + h].z, raw[r + h].w};
       rb[h] = 0;
       g[h] = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const uint32_t m = v[k] & 0x00ff00ffu;
-        const uint32_t gg = (v[k] >> 8) & 0xffu;
+        const uint32_t m = v[k] & mrb;
+        const uint32_t gg = v[k] & mg;
         st.crb[k] += m;
         st.cg[k] += gg;
         rb[h] += m;
@@ -171,15 +187,18 @@ __device__ __forceinline__ void reduce_rows(const EncodeArgs &a, ReduceState &st
       }
     }
     // strip sums end up in lane 63; the two rows' greens share one scan
-    const uint32_t t0 = wave_scan_incl(rb[0]);
-    const uint32_t t1 = wave_scan_incl(rb[1]);
-    const uint32_t tg = wave_scan_incl(g[0] | (g[1] << 16));
-    if (lane == 63) {
+    uint32_t t0 = rb[0], t1 = rb[1], tg = (g[0] >> 8) | (g[1] << 8);
+    if (!(a.ablate & 1)) {
+      t0 = wave_scan_incl(t0);
+      t1 = wave_scan_incl(t1);
+      tg = wave_scan_incl(tg);
+    }
+    if (lane == 63 && y + r < y_stop && !(a.ablate & 2)) {
       uint32_t *rs = a.rowsum + ((size_t)strip * a.height + (y + r)) * 3;
       rs[0] = t0 & 0xffffu;
       rs[1] = tg & 0xffffu;
       rs[2] = t0 >> 16;
-      if (y + r + 1 < y_hi) {
+      if (y + r + 1 < y_stop) {
         rs[3] = t1 & 0xffffu;
         rs[4] = tg >> 16;
         rs[5] = t1 >> 16;
@@ -196,7 +215,7 @@ __device__ __forceinline__ void reduce_flush_band(ReduceState &st) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     st.col[3 * k + 0] += st.crb[k] & 0xffffu;
-    st.col[3 * k + 1] += st.cg[k];
+    st.col[3 * k + 1] += st.cg[k] >> 8;
     st.col[3 * k + 2] += st.crb[k] >> 16;
     st.crb[k] = 0;
     st.cg[k] = 0;
@@ -206,15 +225,12 @@ __device__ __forceinline__ void reduce_flush_band(ReduceState &st) {
 template <bool VEC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
     const EncodeArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t part[2][kWavesPerBlock][64 * 12];
-  __shared__ uint32_t tpart[2][kWavesPerBlock][4];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int strip = blockIdx.x;
+  const int strip = __builtin_amdgcn_readfirstlane(
+      (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
   const int sb = blockIdx.y;
+  if (strip >= a.nstrips) return;
   const int x0 = strip * kStripPx + lane * kLanePx;
-  const int quarter = a.band_rows / kWavesPerBlock;
-  const int per_band = (quarter + kRowUnroll - 1) / kRowUnroll;  // batches per band and wave
 
   ReduceState st;
 #pragma unroll
@@ -225,66 +241,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
 
   const int band0 = sb * a.sb_bands;
   const int band_end = min(band0 + a.sb_bands, a.nbands);
-  const int steps = (band_end - band0) * per_band;
-  // step t -> rows [y, y_hi) of this wave
-  auto rows_of = [&](int t, int &y, int &y_hi) {
-    const int band = band0 + t / per_band;
-    const int q_lo = band * a.band_rows + wave * quarter;
-    y = q_lo + (t % per_band) * kRowUnroll;
-    y_hi = (t < steps) ? min(min(q_lo + quarter, (band + 1) * a.band_rows), a.height) : 0;
-  };
-  // at a band's first step: publish this wave's running column sums, let one
-  // wave add the four and store the row of sums above the band
-  auto publish = [&](int band) {
-    const int buf = (band - band0) & 1;
-    store12(&part[buf][wave][lane * 12], st.col);
+  const int y_stop = min(band_end * a.band_rows, a.height);
+
+  // band_rows is 16, 32 or 64: an even number of batches per band, so the two
+  // row buffers alternate with static indices
+  uint4 buf_a[kRowUnroll], buf_b[kRowUnroll];
+  reduce_load_batch<VEC>(a, buf_a, band0 * a.band_rows, x0);
+  for (int band = band0; band < band_end; ++band) {
+    store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, st.col);
+    const int y_band_end = (band + 1) * a.band_rows;
+    for (int y = band * a.band_rows; y < y_band_end; y += 2 * kRowUnroll) {
+      reduce_load_batch<VEC>(a, buf_b, y + kRowUnroll, x0);
+      reduce_rows(a, st, buf_a, y, y_stop, strip, lane);
+      reduce_load_batch<VEC>(a, buf_a, y + 2 * kRowUnroll, x0);
+      reduce_rows(a, st, buf_b, y + kRowUnroll, y_stop, strip, lane);
+    }
+    reduce_flush_band(st);
     if (lane == 63) {
-      tpart[buf ^ 1][wave][0] = st.tile[0];  // totals of the band just finished
-      tpart[buf ^ 1][wave][1] = st.tile[1];
-      tpart[buf ^ 1][wave][2] = st.tile[2];
+      uint32_t *tt = a.tiletotal + ((size_t)strip * a.nbands + band) * 3;
+      tt[0] = st.tile[0];
+      tt[1] = st.tile[1];
+      tt[2] = st.tile[2];
     }
     st.tile[0] = st.tile[1] = st.tile[2] = 0;
-    __syncthreads();
-    if (wave == ((band - band0) & 3)) {
-      uint32_t sum[12], t[12];
-      load12(&part[buf][0][lane * 12], sum);
-#pragma unroll
-      for (int w = 1; w < kWavesPerBlock; ++w) {
-        load12(&part[buf][w][lane * 12], t);
-#pragma unroll
-        for (int e = 0; e < 12; ++e) sum[e] += t[e];
-      }
-      uint32_t *dst = (band < band_end ? a.lp + (size_t)band * a.wp3
-                                       : a.sbtotal + (size_t)sb * a.wp3) +
-                      (size_t)x0 * 3;
-      store12(dst, sum);
-      if (band > band0 && lane < 3)
-        a.tiletotal[((size_t)strip * a.nbands + (band - 1)) * 3 + lane] =
-            tpart[buf ^ 1][0][lane] + tpart[buf ^ 1][1][lane] +
-            tpart[buf ^ 1][2][lane] + tpart[buf ^ 1][3][lane];
-    }
-  };
-
-  uint4 buf_a[kRowUnroll], buf_b[kRowUnroll];
-  int y, y_hi, ny, ny_hi;
-  rows_of(0, y, y_hi);
-  reduce_load_batch<VEC>(a, buf_a, y, y_hi, x0);
-  for (int t = 0; t < steps; t += 2) {
-    // even step: sum buf_a while buf_b loads
-    rows_of(t + 1, ny, ny_hi);
-    reduce_load_batch<VEC>(a, buf_b, ny, ny_hi, x0);
-    if (t % per_band == 0) publish(band0 + t / per_band);
-    reduce_rows(a, st, buf_a, y, y_hi, strip, lane);
-    if ((t + 1) % per_band == 0) reduce_flush_band(st);
-    if (t + 1 >= steps) break;
-    // odd step: sum buf_b while buf_a loads
-    rows_of(t + 2, y, y_hi);
-    reduce_load_batch<VEC>(a, buf_a, y, y_hi, x0);
-    if ((t + 1) % per_band == 0) publish(band0 + (t + 1) / per_band);
-    reduce_rows(a, st, buf_b, ny, ny_hi, strip, lane);
-    if ((t + 2) % per_band == 0) reduce_flush_band(st);
   }
-  publish(band_end);  // super-band totals and the last band's tile total
+  store12(a.sbtotal + (size_t)sb * a.wp3 + (size_t)x0 * 3, st.col);
 }
 
 // ---- K2: exclusive prefixes of the carry arrays ------------------------------
@@ -536,6 +517,7 @@ extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
   a.tiletotal = p.tiletotal;
   a.tprefix = p.tprefix;
   a.reverse = ctx->opt_reverse_tiles;
+  a.ablate = ctx->opt_ablate;
 
   const bool prof = f360::take_profile_slot(ctx);
   const bool vec = bpp == 4 && (width % 4) == 0 && (linesize % 16) == 0 &&
@@ -546,10 +528,10 @@ extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
   {
     f360::KernelSpan span(ctx, f360::kSatReduce, prof);
     if (vec)
-      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(p.nstrips, p.nsb), block, 0,
-                         ctx->stream, a);
+      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(bx, p.nsb), block, 0, ctx->stream,
+                         a);
     else
-      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(p.nstrips, p.nsb), block, 0,
+      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(bx, p.nsb), block, 0,
                          ctx->stream, a);
   }
 

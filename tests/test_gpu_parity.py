@@ -155,7 +155,7 @@ def test_satdec_grid_and_sample_match_oracle(f360, gpu_ctx, oracle, w, h):
     dec.InitializeGrid(rw, rh, w, h)
     assert np.array_equal(dec.export_grid(rw, rh), grid)
     gazes = GAZES + EXTRA_GAZES + [lissajous(k) for k in (1, 17, 40)]
-    for variant in (0, 1):
+    for variant in (0, 1, 2, 3):
         gpu_ctx.set_option("sample.variant", variant)
         for (cx, cy) in gazes:
             for pad in (0, 32):
@@ -163,7 +163,7 @@ def test_satdec_grid_and_sample_match_oracle(f360, gpu_ctx, oracle, w, h):
                 oracle.satdec_sample_rect(want, rw, rh, 4 * rw + pad, sat, w, h, grid, cx, cy)
                 got = run_sample_rect(f360, gpu_ctx, dec, sat, w, h, rw, rh, cx, cy, pad=pad)
                 assert np.array_equal(got, want), (variant, cx, cy, pad)
-    gpu_ctx.set_option("sample.variant", 0)
+    gpu_ctx.set_option("sample.variant", 1)
     dec.close()
 
 
@@ -192,14 +192,14 @@ def test_encode_sample_pipeline_full_size(f360, gpu_ctx, oracle, golden_digests,
     sat = gpu_ctx.malloc(w * h * 12)
     dst = gpu_ctx.malloc(rw * rh * 4)
     enc.EncodeFrameGPU(sat.ptr, src.ptr, w, h, 4 * w)
-    for variant in (0, 1):
+    for variant in (0, 1, 2, 3):
         gpu_ctx.set_option("sample.variant", variant)
         for k, (cx, cy) in enumerate(golden_digests["gazes"][:3]):
             dst.fill(0xA5)
             dec.SampleFrameRectGPU(dst.ptr, rw, rh, 4 * rw, sat.ptr, (w, h), cx, cy)
             got = dst.copy_to_host(np.uint8, (rh, 4 * rw))
             assert f"{oracle.fnv1a64(got):016x}" == ent[f"sample_rect_{k}"], (variant, k)
-    gpu_ctx.set_option("sample.variant", 0)
+    gpu_ctx.set_option("sample.variant", 1)
     src.copy_from_host(np.full((h, 4 * w), 255, dtype=np.uint8))
     enc.EncodeFrameGPU(sat.ptr, src.ptr, w, h, 4 * w)
     dst.fill(0)
