@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench_configs.py -- the BASELINE.json configs that are not the headline benchmark (bench.py).
+
+    python bench_configs.py [--config 2|3|5|all] [--quick]
+
+config 2  300 frames 1920x1080 (LCG seeds 1..300, Lissajous gaze): SAT encode + SAT sample_rect on
+          1 GPU; every frame's SAT and reduced frame is then compared with the oracle (digests).
+config 3  3840x1920: log-polar forward warp + bilinear inverse over the 17x9 gaze lattice; a few
+          gaze points are compared with the oracle (+-1 per 8-bit channel).
+config 5  8K streaming loop at 60 fps with 8 gaze clients (examples/send_frame_loop_synth, the
+          reference's SendFrameLoop with synthetic source / null sink): latency p50/p99, Mpix/s.
+Prints one JSON line per config; RESULTS.md holds the numbers measured for this round.
+"""
+import argparse
+import json
+import math
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
+
+import numpy as np  # noqa: E402
+
+
+def reduced(n):
+    return 16 * math.ceil(n / 1.8 / 16)
+
+
+def lissajous(k):
+    return (np.float32(0.5 + 0.45 * math.sin(2 * math.pi * k / 97)),
+            np.float32(0.5 + 0.35 * math.sin(2 * math.pi * k / 61)))
+
+
+def config2(f360, ob, quick):
+    w, h, n = 1920, 1080, (30 if quick else 300)
+    rw, rh = reduced(w), reduced(h)
+    with f360.Context(0) as ctx:
+        enc, dec = f360.SATEncoder(ctx), f360.SATDecoder(ctx)
+        dec.InitializeGrid(rw, rh, w, h)
+        frames = [ob.lcg_frame(w, h, 1 + k) for k in range(n)]
+        src = [ctx.upload(f) for f in frames]
+        sat = [ctx.malloc(w * h * 12) for _ in range(n)]
+        red = [ctx.malloc(rw * rh * 4) for _ in range(n)]
+        for r in red:
+            r.fill(0)
+        gaze = [lissajous(k) for k in range(n)]
+
+        def run():
+            for k in range(n):
+                enc.EncodeFrameGPU(sat[k].ptr, src[k].ptr, w, h, 4 * w)
+                dec.SampleFrameRectGPU(red[k].ptr, rw, rh, 4 * rw, sat[k].ptr, (w, h), gaze[k][0],
+                                       gaze[k][1])
+        run()
+        ctx.finish()
+        t0 = time.perf_counter()
+        run()
+        ctx.finish()
+        dt = time.perf_counter() - t0
+        grid = ob.satdec_grid(rw, rh, w, h)
+        bad = 0
+        for k in range(n):
+            want_sat = ob.sat_encode(frames[k], w, h, 4 * w)
+            want_red = np.zeros((rh, 4 * rw), dtype=np.uint8)
+            ob.satdec_sample_rect(want_red, rw, rh, 4 * rw, want_sat, w, h, grid, gaze[k][0], gaze[k][1])
+            ok = (ob.fnv1a64(sat[k].copy_to_host(np.uint32, (h, w, 3))) == ob.fnv1a64(want_sat) and
+                  ob.fnv1a64(red[k].copy_to_host(np.uint8, (rh, 4 * rw))) == ob.fnv1a64(want_red))
+            bad += 0 if ok else 1
+        dec.close()
+    enc_b = 16 * w * h
+    smp_b = 12 * (rw + 1) * (rh + 1) + 4 * rw * rh
+    return {"config": 2, "workload": f"{n} frames {w}x{h} SAT encode + sample_rect to {rw}x{rh}",
+            "mpix_per_s": round(n * w * h / 1e6 / dt, 1), "us_per_frame": round(1e6 * dt / n, 2),
+            "hbm_frac_algorithmic": round((enc_b + smp_b) * n / dt / 8e12, 4),
+            "parity": f"{n - bad}/{n} frames SAT and reduced frame bit-exact vs oracle"}
+
+
+def config3(f360, ob, quick):
+    w, h = 3840, 1920
+    rw, rh = reduced(w), reduced(h)
+    y, x = np.mgrid[0:h, 0:w]
+    frame = np.zeros((h, w, 4), dtype=np.uint8)
+    frame[:, :, 0] = x * 255 // (w - 1)
+    frame[:, :, 1] = y * 255 // (h - 1)
+    frame[:, :, 2] = (((x // 16) + (y // 16)) % 2) * 40 + 100
+    lattice = [(cx / 16.0, cy / 8.0) for cy in range(9) for cx in range(17)]
+    if quick:
+        lattice = lattice[::9]
+    with f360.Context(0) as ctx:
+        smp = f360.ImageSampler(ctx)
+        smp.InitializeLogpolarGrid(rw, rh, w, h)
+        src, red, full = ctx.upload(frame), ctx.malloc(rw * rh * 4), ctx.malloc(w * h * 4)
+        red.fill(0)
+
+        def run():
+            for (cx, cy) in lattice:
+                smp.SampleFrameLogPolarGPU(red.ptr, rw, rh, 4 * rw, src.ptr, w, h, 4 * w, cx, cy)
+                smp.InterpolateFrameLogPolarGPU(full.ptr, w, h, 4 * w, red.ptr, rw, rh, 4 * rw, cx, cy)
+        run()
+        ctx.finish()
+        t0 = time.perf_counter()
+        run()
+        ctx.finish()
+        dt = time.perf_counter() - t0
+        lpg = ob.is_logpolar_grid(rw, rh, w, h)
+        worst, over = 0, 0
+        for (cx, cy) in ([(0.5, 0.5)] if quick else [(0.5, 0.5), (0.0, 1.0), (0.8125, 0.25)]):
+            red.fill(0)
+            smp.SampleFrameLogPolarGPU(red.ptr, rw, rh, 4 * rw, src.ptr, w, h, 4 * w, cx, cy)
+            smp.InterpolateFrameLogPolarGPU(full.ptr, w, h, 4 * w, red.ptr, rw, rh, 4 * rw, cx, cy)
+            want_red = np.zeros((rh, 4 * rw), dtype=np.uint8)
+            ob.is_sample_logpolar(want_red, rw, rh, 4 * rw, frame, w, h, 4 * w, lpg, cx, cy)
+            want = ob.is_interpolate_logpolar(want_red.reshape(rh, rw, 4), w, h, rw, rh, cx, cy)
+            got = full.copy_to_host(np.uint8, (h, w, 4))
+            d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+            worst = max(worst, int(d.max()))
+            over += int((d > 1).sum())
+            assert np.array_equal(red.copy_to_host(np.uint8, (rh, 4 * rw)), want_red)
+        smp.close()
+    n = len(lattice)
+    return {"config": 3, "workload": f"{w}x{h} log-polar forward + bilinear inverse, {n} gaze points",
+            "mpix_per_s": round(n * w * h / 1e6 / dt, 1), "us_per_gaze": round(1e6 * dt / n, 2),
+            "hbm_frac_algorithmic": round((4 * w * h + 8 * rw * rh + 4 * w * h) * n / dt / 8e12, 4),
+            "parity": f"forward warp bit-exact; inverse max |diff| {worst}, {over} channel values beyond +-1"}
+
+
+def config5(quick):
+    exe = os.path.join(REPO, "examples", "send_frame_loop_synth")
+    subprocess.run(["make", "-C", os.path.join(REPO, "examples")], check=True, capture_output=True)
+    out = []
+    for clients in ((1, 8) if not quick else (1,)):
+        r = subprocess.run([exe, str(clients), "60", "30" if quick else "120", "7680", "3840"],
+                           capture_output=True, text=True, timeout=600)
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        res["config"] = 5
+        out.append(res)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="all")
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    import f360_amd as f360
+    import oracle_binding as ob
+    if f360.device_count() < 1:
+        sys.exit("bench_configs.py: no HIP device visible; there is no CPU fallback")
+    todo = ["2", "3", "5"] if args.config == "all" else [args.config]
+    for c in todo:
+        res = config2(f360, ob, args.quick) if c == "2" else config3(f360, ob, args.quick) if c == "3" \
+            else config5(args.quick)
+        for r in (res if isinstance(res, list) else [res]):
+            print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()

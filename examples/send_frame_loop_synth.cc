@@ -1,0 +1,189 @@
+// send_frame_loop_synth.cc -- the reference's per-client streaming loop on the HIP engine.
+//
+// Mirrors VideoServer::InitializeConnectionData + SendFrameLoop
+// (/root/reference/src/video_server.cc:45-86,197-427): one thread and one
+// OpenCLManager / SATEncoder / SATDecoder per client; per tick
+//     get frame -> cl::copy H2D -> EncodeFrameGPU -> clFinish
+//     -> sleep until the tick -> read the LATEST gaze -> SampleFrameRectGPU -> cl::copy D2H
+//     -> encoder sink
+// with a synthetic source (pre-staged pinned frames instead of VideoDecoder), the gaze
+// coming from a GazeViewPoints trace (instead of websocket messages) and a null sink
+// (instead of NVENC + fMP4 + websocket).  Reports per-frame busy latency (everything but
+// the sleep) and aggregate input Mpixels/s: BASELINE.json config 5.
+//
+//   ./send_frame_loop_synth <clients> <fps> <frames> <width> <height> [trace.txt] [gpus]
+// client c runs on GPU c % gpus.  Prints one JSON line.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "f360/gaze_view_points.h"
+#include "f360/parameters.h"
+#include "f360/sat_decoder.h"
+#include "f360/sat_encoder.h"
+
+struct CodecContext {
+  int width, height;
+};
+
+struct ClientResult {
+  std::vector<double> latency_ms;
+  double loop_s = 0;  // first tick .. last frame delivered (set-up excluded)
+  uint64_t last_digest = 0;
+  float last_gaze[2] = {0, 0};
+  int frames = 0;
+};
+
+static uint64_t fnv1a64(const void *p, size_t n) {
+  const uint8_t *b = (const uint8_t *)p;
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (size_t k = 0; k < n; ++k) {
+    h ^= b[k];
+    h *= 0x100000001b3ull;
+  }
+  return h;
+}
+
+static void client_loop(int client, int device, double fps, int frames, int width, int height,
+                        const GazeViewPoints *trace, ClientResult *out) {
+  using clock = std::chrono::high_resolution_clock;
+  // ---- InitializeConnectionData (video_server.cc:62-66) --------------------------------
+  OpenCLManager cl_manager;
+  cl_manager.device_index = device;
+  if (cl_manager.InitializeContext() != 0) return;
+  SATEncoder sat_encoder(&cl_manager);
+  SATDecoder sat_decoder(&cl_manager);
+  CodecContext codec = {width, height};
+  const int out_w = f360_reduced_size(width), out_h = f360_reduced_size(height);
+  sat_decoder.InitializeGrid(out_w, out_h, width, height);
+
+  // ---- SendFrameLoop buffers (video_server.cc:224-232) -----------------------------------
+  const int linesize = 4 * width, out_linesize = 4 * out_w;
+  const size_t cl_source_frame_size = (size_t)linesize * height;
+  cl::Buffer cl_source_frame(cl_manager.context, CL_MEM_READ_WRITE, cl_source_frame_size);
+  cl::Buffer cl_sat_buffer(cl_manager.context, CL_MEM_READ_WRITE,
+                           (size_t)3 * width * height * sizeof(uint32_t));
+  const size_t cl_output_buffer_size = (size_t)out_linesize * out_h;
+  cl::Buffer cl_output_buffer(cl_manager.context, CL_MEM_READ_WRITE, cl_output_buffer_size);
+
+  // synthetic decoder: a few pre-staged pinned frames, cycled
+  const int pool = 3;
+  uint8_t *staged[pool];
+  uint8_t *output_frame = nullptr;
+  for (int k = 0; k < pool; ++k) {
+    if (f360_host_alloc_pinned(cl_source_frame_size, (void **)&staged[k]) != F360_OK) return;
+    uint32_t s = 12345u + 1000u * client + k;
+    for (size_t b = 0; b < cl_source_frame_size; ++b) {
+      s = s * 1664525u + 1013904223u;
+      staged[k][b] = (uint8_t)(s >> 24);
+    }
+  }
+  if (f360_host_alloc_pinned(cl_output_buffer_size, (void **)&output_frame) != F360_OK) return;
+  std::memset(output_frame, 0, cl_output_buffer_size);
+  cl::copy(cl_manager.command_queue, output_frame, output_frame + cl_output_buffer_size,
+           cl_output_buffer);
+
+  auto checkpoint_time = clock::now();
+  const auto loop_start = checkpoint_time;
+  const double tick_ms = 1000.0 / fps;
+  for (int frame_number = 0; frame_number < frames; ++frame_number) {
+    const auto t0 = clock::now();
+    uint8_t *rgb = staged[frame_number % pool];  // video_decoder->GetFrame(rgb_frame, RGB0)
+    cl_int ret = cl::copy(cl_manager.command_queue, rgb, rgb + cl_source_frame_size, cl_source_frame);
+    sat_encoder.EncodeFrameGPU(cl_sat_buffer(), cl_source_frame(), width, height, linesize);
+    clFlush(cl_manager.command_queue());
+    clFinish(cl_manager.command_queue());
+    const auto t1 = clock::now();
+
+    // Sleep until we're ready (video_server.cc:310-318)
+    const double since =
+        std::chrono::duration<double, std::milli>(clock::now() - checkpoint_time).count();
+    if (tick_ms - since > 0)
+      std::this_thread::sleep_for(std::chrono::duration<double, std::milli>(tick_ms - since));
+
+    // Done sleeping. Grab the latest gaze position (video_server.cc:325-328)
+    float center_x = 0.5f, center_y = 0.5f;
+    if (trace && !trace->points.empty()) {
+      const auto &p = trace->points[(size_t)(frame_number + 17 * client) % trace->points.size()];
+      center_x = p.gaze_point[0];
+      center_y = p.gaze_point[1];
+    }
+    checkpoint_time = clock::now();
+    const auto t2 = clock::now();
+    sat_decoder.SampleFrameRectGPU(cl_output_buffer(), out_w, out_h, out_linesize, cl_sat_buffer(),
+                                   &codec, center_x, center_y);
+    ret |= cl::copy(cl_manager.command_queue, cl_output_buffer, output_frame,
+                    output_frame + cl_output_buffer_size);
+    const auto t3 = clock::now();
+    if (ret != CL_SUCCESS) {
+      std::cerr << "Failed to copy output frame out. " << ret << std::endl;
+      exit(EXIT_FAILURE);
+    }
+    // video_encoder->EncodeFrame(...) / websocket send: null sink
+    out->latency_ms.push_back(std::chrono::duration<double, std::milli>((t1 - t0) + (t3 - t2)).count());
+    out->last_gaze[0] = center_x;
+    out->last_gaze[1] = center_y;
+    ++out->frames;
+  }
+  out->loop_s = std::chrono::duration<double>(clock::now() - loop_start).count();
+  out->last_digest = fnv1a64(output_frame, cl_output_buffer_size);
+  for (int k = 0; k < pool; ++k) f360_host_free_pinned(staged[k]);
+  f360_host_free_pinned(output_frame);
+}
+
+int main(int argc, char **argv) {
+  const int clients = argc > 1 ? atoi(argv[1]) : 8;
+  const double fps = argc > 2 ? atof(argv[2]) : 60.0;
+  const int frames = argc > 3 ? atoi(argv[3]) : 120;
+  const int width = argc > 4 ? atoi(argv[4]) : 7680;
+  const int height = argc > 5 ? atoi(argv[5]) : 3840;
+  const std::string trace_path = argc > 6 ? argv[6] : "";
+  int gpus = argc > 7 ? atoi(argv[7]) : 0;
+  if (gpus <= 0 && f360_device_count(&gpus) != F360_OK) {
+    std::cerr << f360_last_error_string() << std::endl;
+    return EXIT_FAILURE;
+  }
+  GazeViewPoints trace;
+  if (!trace_path.empty()) trace = GazeViewPoints(trace_path);
+
+  std::vector<ClientResult> results((size_t)clients);
+  std::vector<std::thread> threads;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  for (int c = 0; c < clients; ++c)
+    threads.emplace_back(client_loop, c, c % gpus, fps, frames, width, height,
+                         trace.points.empty() ? nullptr : &trace, &results[(size_t)c]);
+  for (auto &t : threads) t.join();
+  const double wall_s =
+      std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+
+  std::vector<double> all;
+  long total_frames = 0;
+  double fps_sum = 0, loop_max = 0;
+  for (const auto &r : results) {
+    if (r.loop_s > 0) fps_sum += r.frames / r.loop_s;
+    loop_max = std::max(loop_max, r.loop_s);
+    // skip each client's first frame (context warm-up)
+    for (size_t k = 1; k < r.latency_ms.size(); ++k) all.push_back(r.latency_ms[k]);
+    total_frames += r.frames;
+  }
+  std::sort(all.begin(), all.end());
+  auto pct = [&](double q) { return all.empty() ? 0.0 : all[(size_t)std::min<double>(all.size() - 1, q * all.size())]; };
+  printf("{\"clients\": %d, \"gpus\": %d, \"fps_target\": %.1f, \"frames_per_client\": %d, \"width\": %d, "
+         "\"height\": %d, \"wall_s_with_setup\": %.3f, \"fps_achieved_per_client\": %.2f, \"mpix_per_s\": %.1f, "
+         "\"latency_ms_p50\": %.3f, \"latency_ms_p99\": %.3f, \"latency_ms_max\": %.3f, "
+         "\"client0_last_gaze\": [%.9g, %.9g], \"client0_last_digest\": \"%016llx\"}\n",
+         clients, gpus, fps, frames, width, height, wall_s, fps_sum / clients,
+         loop_max > 0 ? (double)total_frames * width * height / 1e6 / loop_max : 0.0, pct(0.50), pct(0.99),
+         all.empty() ? 0.0 : all.back(), results[0].last_gaze[0], results[0].last_gaze[1],
+         (unsigned long long)results[0].last_digest);
+  return EXIT_SUCCESS;
+}

@@ -92,6 +92,8 @@ _SIGNATURES = {
     "f360_satdec_export_grid": (c_int, [c_void_p, c_void_p]),
     "f360_satdec_sample_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                         c_int, c_int, c_float, c_float]),
+    "f360_satdec_sample_rect_batch": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
+                                              c_int, c_void_p, c_int, c_int, POINTER(c_float)]),
     "f360_satdec_interpolate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_void_p, c_int, c_int, c_int, c_float,
                                              c_float]),
@@ -346,6 +348,20 @@ class SATDecoder:
         _check(lib().f360_satdec_sample_rect(self._h, _p(cl_target_buffer), target_width,
                                              target_height, target_linesize,
                                              _p(cl_source_buffer), w, h, center_x, center_y))
+
+    def SampleFrameRectGPUBatch(self, cl_target_buffers, target_width, target_height,
+                                target_linesize, cl_source_buffer, codec_ctx, centers) -> None:
+        """One launch for several gaze points against one table; `centers`
+        is a list of (center_x, center_y), `cl_target_buffers` a list of device pointers."""
+        self._need("SampleFrameRectGPUBatch")
+        w, h = (codec_ctx if isinstance(codec_ctx, tuple)
+                else (codec_ctx.width, codec_ctx.height))
+        n = len(cl_target_buffers)
+        ptrs = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        xy = (c_float * (2 * n))(*[float(v) for c in centers for v in c])
+        _check(lib().f360_satdec_sample_rect_batch(self._h, ptrs, n, target_width,
+                                                   target_height, target_linesize,
+                                                   _p(cl_source_buffer), w, h, xy))
 
     def InterpolateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
                                 target_linesize, cl_source_buffer, source_width,

@@ -236,6 +236,28 @@ __global__ __launch_bounds__(256) void sample_rect_walk_kernel(const SampleArgs 
   walk_body(a, c0, 0, a.out_w, j0, min(j0 + rows, a.out_h));
 }
 
+// Several gaze points against ONE table (clients that watch the same video share the
+// encode): blockIdx.z selects the client.
+constexpr int kMaxBatch = 16;
+struct SampleBatch {
+  uint8_t *dst[kMaxBatch];
+  int cxp[kMaxBatch], cyp[kMaxBatch];
+};
+
+__global__ __launch_bounds__(256) void sample_rect_walk_batch_kernel(SampleArgs a,
+                                                                      const SampleBatch b,
+                                                                      int rows) {
+  const int c0 = __builtin_amdgcn_readfirstlane(
+      ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kWalkCols);
+  if (c0 >= a.out_w) return;  // whole wave
+  const int z = blockIdx.z;
+  a.dst = b.dst[z];
+  a.cxp = b.cxp[z];
+  a.cyp = b.cyp[z];
+  const int j0 = (int)blockIdx.y * rows;
+  walk_body(a, c0, 0, a.out_w, j0, min(j0 + rows, a.out_h));
+}
+
 // Variant 2 ("row streaming").  At 8K a gaze touches ~1900 table rows and every
 // 128-byte line of each of them, yet a gather uses 12 bytes of each 64-byte
 // request in the periphery.  Here a wave owns a 256-texel source tile and a run
@@ -803,6 +825,59 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
                        source_width, source_height, dec->gx_dev.as<int16_t>(),
                        dec->gy_dev.as<int16_t>(), cxp, cyp);
   }
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                  int count, int target_width, int target_height,
+                                  int target_linesize, const uint32_t *sat_dev,
+                                  int source_width, int source_height,
+                                  const float *centers_xy) {
+  F360_REQUIRE(dec, "f360_satdec_sample_rect_batch: null decoder");
+  F360_REQUIRE(targets_dev && sat_dev && centers_xy,
+               "f360_satdec_sample_rect_batch: null buffer");
+  F360_REQUIRE(count >= 1 && count <= kMaxBatch,
+               "f360_satdec_sample_rect_batch: count %d outside 1..%d", count, kMaxBatch);
+  F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
+                   source_height >= 2 && target_linesize >= 4 * target_width,
+               "f360_satdec_sample_rect_batch: bad geometry");
+  F360_REQUIRE((size_t)source_width * source_height * 12 < ((size_t)1 << 32),
+               "f360_satdec_sample_rect_batch: table too large");
+  if (!dec->gx_dev.p) {
+    int st = f360_satdec_initialize_grid(dec, target_width, target_height, source_width,
+                                         source_height);
+    if (st != F360_OK) return st;
+  }
+  F360_REQUIRE(dec->gw == target_width && dec->gh == target_height,
+               "f360_satdec_sample_rect_batch: grid was initialised for %dx%d", dec->gw,
+               dec->gh);
+  SampleBatch b;
+  for (int k = 0; k < kMaxBatch; ++k) {
+    const int q = k < count ? k : 0;
+    F360_REQUIRE(targets_dev[q], "f360_satdec_sample_rect_batch: null target %d", q);
+    F360_REQUIRE(std::fabs(centers_xy[2 * q]) <= 16.0f && std::fabs(centers_xy[2 * q + 1]) <= 16.0f,
+                 "f360_satdec_sample_rect_batch: gaze centre out of range");
+    b.dst[k] = targets_dev[q];
+    b.cxp[k] = (int)(centers_xy[2 * q] * (float)source_width);
+    b.cyp[k] = (int)(centers_xy[2 * q + 1] * (float)source_height);
+  }
+  SampleArgs sa = {};
+  sa.out_w = target_width;
+  sa.out_h = target_height;
+  sa.out_stride_px = target_linesize / 4;
+  sa.sat = sat_dev;
+  sa.src_w = source_width;
+  sa.src_h = source_height;
+  sa.gx = dec->gx_dev.as<int16_t>();
+  sa.gy = dec->gy_dev.as<int16_t>();
+  f360_ctx *ctx = dec->ctx;
+  const int rows = ctx->opt_walk_rows;
+  const dim3 grid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),
+                  (target_height + rows - 1) / rows, count);
+  f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
+  hipLaunchKernelGGL(sample_rect_walk_batch_kernel, grid, dim3(256), 0, ctx->stream, sa, b,
+                     rows);
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

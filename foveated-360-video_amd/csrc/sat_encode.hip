@@ -434,15 +434,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
 
 int ensure_plan(f360_ctx *ctx, int width, int height) {
   f360::SatEncodePlan &p = ctx->enc;
-  if (p.width == width && p.height == height &&
-      p.band_rows == ctx->opt_band_rows && p.sb_bands == ctx->opt_sb_bands &&
-      p.ws.p)
+  // band height: the largest of 64 / 32 / 16 rows that still yields enough tiles (one wave
+  // each in the writer) to fill 256 CUs -- 64 at 7680x3840, 16 at 3840x1920 and below
+  int band_rows = ctx->opt_band_rows;
+  if (band_rows == 0) {
+    const int strips = (width + kStripPx - 1) / kStripPx;
+    band_rows = 16;
+    for (int cand : {64, 32})
+      if ((long)strips * ((height + cand - 1) / cand) >= 1500) {
+        band_rows = cand;
+        break;
+      }
+  }
+  if (p.width == width && p.height == height && p.band_rows == band_rows &&
+      p.sb_bands == ctx->opt_sb_bands && p.ws.p)
     return F360_OK;
   // A geometry change re-carves the scratch; wait for work that may use it.
   if (p.ws.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
   p.width = width;
   p.height = height;
-  p.band_rows = ctx->opt_band_rows;
+  p.band_rows = band_rows;
   p.sb_bands = ctx->opt_sb_bands;
   p.nstrips = (width + kStripPx - 1) / kStripPx;
   p.nbands = (height + p.band_rows - 1) / p.band_rows;

