@@ -536,3 +536,110 @@ def test_send_frame_loop_example(f360, gpu_ctx, oracle, tmp_path):
     oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, oracle.satdec_grid(rw, rh, w, h),
                               float(cx), float(cy))
     assert res["client0_last_digest"] != "0" * 16
+
+
+# --------------------------------------------------------------------- odd geometries / threads
+@pytest.mark.parametrize("w,h,rw,rh", [(64, 32, 16, 16), (200, 120, 33, 77), (512, 96, 300, 20),
+                                       (1280, 720, 720, 400), (48, 48, 64, 64)])
+def test_sampler_variants_on_odd_geometries(f360, gpu_ctx, oracle, w, h, rw, rh):
+    """Reduced sizes that do not follow the 1.8 rule, fewer columns than one wave, targets larger
+    than the source: every sampler variant (the streaming ones fall back when they do not apply)
+    and the un-warp against the oracle."""
+    frame = oracle.lcg_frame(w, h, 404)
+    sat_h = oracle.sat_encode(frame, w, h, 4 * w)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    dec = f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    assert np.array_equal(dec.export_grid(rw, rh), grid)
+    for variant in (0, 1, 2, 3):
+        gpu_ctx.set_option("sample.variant", variant)
+        for (cx, cy) in [(0.5, 0.5), (0.0, 0.0), (0.97, 0.2), (-0.3, 1.2)]:
+            want = np.full((rh, 4 * rw + 8), 0xA5, dtype=np.uint8)
+            oracle.satdec_sample_rect(want, rw, rh, 4 * rw + 8, sat_h, w, h, grid, cx, cy)
+            got = run_sample_rect(f360, gpu_ctx, dec, sat_h, w, h, rw, rh, cx, cy, pad=8)
+            assert np.array_equal(got, want), (variant, cx, cy)
+    gpu_ctx.set_option("sample.variant", 1)
+    red = oracle.lcg_frame(rw, rh, 9).reshape(rh, rw, 4)
+    for (cx, cy) in [(0.5, 0.5), (0.1, 0.9)]:
+        assert np.array_equal(run_interp(f360, gpu_ctx, dec, red, w, h, rw, rh, cx, cy),
+                              oracle.satdec_interpolate_rect(red, w, h, rw, rh, cx, cy))
+    dec.close()
+
+
+def test_one_context_per_thread(f360, oracle):
+    """The reference runs one OpenCLManager + encoder + decoder per connection thread
+    (video_server.cc:62-66); four such threads on one GPU must not disturb each other."""
+    import threading
+    w, h = 960, 540
+    rw, rh = reduced(w), reduced(h)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    errors = []
+
+    def client(idx):
+        try:
+            with f360.Context(0) as ctx:
+                enc, dec = f360.SATEncoder(ctx), f360.SATDecoder(ctx)
+                dec.InitializeGrid(rw, rh, w, h)
+                sat, red = ctx.malloc(w * h * 12), ctx.malloc(rw * rh * 4)
+                for k in range(6):
+                    frame = oracle.lcg_frame(w, h, 100 * idx + k)
+                    src = ctx.upload(frame)
+                    cx, cy = lissajous(7 * idx + k)
+                    red.fill(0x5A)
+                    enc.EncodeFrameGPU(sat.ptr, src.ptr, w, h, 4 * w)
+                    dec.SampleFrameRectGPU(red.ptr, rw, rh, 4 * rw, sat.ptr, (w, h), cx, cy)
+                    got = red.copy_to_host(np.uint8, (rh, 4 * rw))
+                    want = np.full((rh, 4 * rw), 0x5A, dtype=np.uint8)
+                    oracle.satdec_sample_rect(want, rw, rh, 4 * rw, oracle.sat_encode(frame, w, h, 4 * w),
+                                              w, h, grid, cx, cy)
+                    if not np.array_equal(got, want):
+                        errors.append((idx, k))
+                    src.free()
+                dec.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_encode_sample_inside_a_hip_graph(f360, oracle):
+    """The launch functions allocate nothing once prepared, so the path can be captured into a
+    hipGraph (here through torch's CUDAGraph on the stream the context borrows) and replayed."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test without a GPU")
+    w, h = 1280, 640
+    rw, rh = reduced(w), reduced(h)
+    dev = torch.device("cuda", 0)
+    frame = torch.from_numpy(oracle.lcg_frame(w, h, 77)).to(dev)
+    sat = torch.zeros((h, w, 3), dtype=torch.int32, device=dev)
+    red = torch.full((rh, 4 * rw), 0xA5, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        ctx = f360.Context(0, stream=side.cuda_stream)
+        enc, dec = f360.SATEncoder(ctx), f360.SATDecoder(ctx)
+        dec.InitializeGrid(rw, rh, w, h)
+        f360._check(f360.lib().f360_sat_encode_prepare(ctx.handle, w, h))
+        enc.EncodeFrameGPU(sat.data_ptr(), frame.data_ptr(), w, h, 4 * w)  # warm-up, eager
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            enc.EncodeFrameGPU(sat.data_ptr(), frame.data_ptr(), w, h, 4 * w)
+            dec.SampleFrameRectGPU(red.data_ptr(), rw, rh, 4 * rw, sat.data_ptr(), (w, h), 0.65, 0.75)
+        sat.zero_()
+        frame.copy_(torch.from_numpy(oracle.lcg_frame(w, h, 78)).to(dev))  # new input, same graph
+        g.replay()
+        torch.cuda.synchronize(dev)
+    want_sat = oracle.sat_encode(oracle.lcg_frame(w, h, 78), w, h, 4 * w)
+    want_red = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+    oracle.satdec_sample_rect(want_red, rw, rh, 4 * rw, want_sat, w, h, oracle.satdec_grid(rw, rh, w, h),
+                              0.65, 0.75)
+    assert np.array_equal(sat.cpu().numpy().view(np.uint32), want_sat)
+    assert np.array_equal(red.cpu().numpy(), want_red)
+    dec.close()
+    ctx.close()
