@@ -505,72 +505,135 @@ __global__ __launch_bounds__(256) void decode_kernel(
 // interpolate_rect_kernel (src/sat_decoder_interpolate_kernel.cl:1-152).
 // tx / ty hold, per pixel offset from the gaze centre, the inverse map u, the
 // forward map of u and of its neighbour (host_tables.h: InterpAxisEntry).
-__device__ __forceinline__ float mixf(float a, float b, float t) {
-  return a + (b - a) * t;  // compiled with -ffp-contract=off: never fused
+// Everything the kernel text computes from one axis only (:26-65, :75-142), for one pixel
+// position: the reduced-buffer index of the exact hit, the two bilinear neighbours and the
+// interpolation weight.  `pos` is the (x: already wrapped) coordinate, `entry` its row of the
+// host table, `wrapped` the kernel's x_offset flag (always false for y).
+struct InterpAxis {
+  int exact_idx, lo, hi;
+  float ratio;
+  bool exact;
+};
+__device__ __forceinline__ InterpAxis interp_axis(int pos, int centre, int4 entry, bool wrapped,
+                                                  int out_size, int rsize, int src_size) {
+  const int u = entry.x, dcalc = entry.y, dmin = entry.z, du = entry.w;
+  InterpAxis r;
+  r.exact = dcalc == pos - centre;
+  const int a0 = centre + dmin, a1 = centre + dcalc;
+  const int mn = min(a0, a1), mx = max(a0, a1);
+  int min_u = min(u, u + du), max_u = max(u, u + du);
+  if (mn < 0 && !wrapped) min_u = max_u;  // :105-116
+  if (mx >= out_size && !wrapped) max_u = min_u;
+  r.lo = min(max(min_u + rsize / 2, 0), src_size - 1);
+  r.hi = min(max(max_u + rsize / 2, 0), src_size - 1);
+  r.exact_idx = min(max(u + rsize / 2, 0), src_size - 1);
+  r.ratio = mx == mn ? 0.0f
+                     : fminf(fmaxf((float)(pos - mn) / (float)(mx - mn), 0.0f), 1.0f);
+  return r;
 }
+
+// A lane owns 4 adjacent output columns (their axis records stay in registers, one 16-byte
+// store per row), a wave 256 columns x `rows` rows; the row's axis record is wave-uniform.
+constexpr int kInterpCols = 4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void interpolate_rect_kernel(
     uint32_t *__restrict__ dst, int out_w, int out_h,
     const uint32_t *__restrict__ src, int src_w, int src_h,
     const int4 *__restrict__ tx, int range_x, const int4 *__restrict__ ty,
-    int range_y, int cxp, int cyp) {
-  const int x0 = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x0 >= out_w || y >= out_h) return;
-  int x = x0;
-  bool x_offset = false;
-  if (x - cxp > out_w / 2) {  // :27-33
-    x -= out_w;
-    x_offset = true;
-  } else if (x - cxp < (-out_w) / 2) {
-    x += out_w;
-    x_offset = true;
-  }
-  const int dx = x - cxp, dy = y - cyp;
-  const int4 ex = tx[dx + range_x];  // {u, dcalc, dmin, du}
-  const int4 ey = ty[dy + range_y];
-  const int u = ex.x, v = ey.x;
-  const int rw = src_w, rh = src_h;
-  uint32_t out;
-  if (ex.y == dx && ey.y == dy) {  // :67-72 exact hit -> copy
-    const int r = min(max(v + rh / 2, 0), src_h - 1);
-    const int c = min(max(u + rw / 2, 0), src_w - 1);
-    out = src[(size_t)r * src_w + c] & 0x00ffffffu;
-  } else {
-    const int du = ex.w, dv = ey.w;
-    const int a0 = cxp + ex.z, a1 = cxp + ex.y;
-    const int b0 = cyp + ey.z, b1 = cyp + ey.y;
-    const int min_x = min(a0, a1), max_x = max(a0, a1);
-    const int min_y = min(b0, b1), max_y = max(b0, b1);
-    int min_u = min(u, u + du), max_u = max(u, u + du);
-    int min_v = min(v, v + dv), max_v = max(v, v + dv);
-    if (min_x < 0 && !x_offset) min_u = max_u;  // :105-116
-    if (max_x >= out_w && !x_offset) max_u = min_u;
-    if (min_y < 0) min_v = max_v;
-    if (max_y >= out_h) max_v = min_v;
-    const int r0 = min(max(min_v + rh / 2, 0), src_h - 1);
-    const int r1 = min(max(max_v + rh / 2, 0), src_h - 1);
-    const int c0 = min(max(min_u + rw / 2, 0), src_w - 1);
-    const int c1 = min(max(max_u + rw / 2, 0), src_w - 1);
-    const uint32_t tl = src[(size_t)r0 * src_w + c0];
-    const uint32_t tr = src[(size_t)r0 * src_w + c1];
-    const uint32_t bl = src[(size_t)r1 * src_w + c0];
-    const uint32_t br = src[(size_t)r1 * src_w + c1];
-    const float yr = max_y == min_y
-                         ? 0.0f
-                         : fminf(fmaxf((float)(y - min_y) / (float)(max_y - min_y), 0.0f), 1.0f);
-    const float xr = max_x == min_x
-                         ? 0.0f
-                         : fminf(fmaxf((float)(x - min_x) / (float)(max_x - min_x), 0.0f), 1.0f);
-    out = 0;
+    int range_y, int cxp, int cyp, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int x_base = ((int)blockIdx.x * 64 + lane) * kInterpCols;
+  const int y0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * rows);
+  if (y0 >= out_h) return;
+  const bool vec_store = (out_w % kInterpCols) == 0;
+
+  InterpAxis ax[kInterpCols];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float l = mixf((float)((tl >> (8 * c)) & 0xffu), (float)((bl >> (8 * c)) & 0xffu), yr);
-      const float r = mixf((float)((tr >> (8 * c)) & 0xffu), (float)((br >> (8 * c)) & 0xffu), yr);
-      out |= ((uint32_t)(int)mixf(l, r, xr) & 0xffu) << (8 * c);
+  for (int k = 0; k < kInterpCols; ++k) {
+    int x = min(x_base + k, out_w - 1);
+    bool x_offset = false;
+    if (x - cxp > out_w / 2) {  // :27-33
+      x -= out_w;
+      x_offset = true;
+    } else if (x - cxp < (-out_w) / 2) {
+      x += out_w;
+      x_offset = true;
+    }
+    ax[k] = interp_axis(x, cxp, tx[x - cxp + range_x], x_offset, out_w, src_w, src_w);
+  }
+
+  // 32-bit byte offsets into the reduced frame (it is far below 4 GiB)
+  uint32_t off_lo[kInterpCols], off_hi[kInterpCols], off_ex[kInterpCols];
+  bool all_exact_x = true;
+#pragma unroll
+  for (int k = 0; k < kInterpCols; ++k) {
+    off_lo[k] = (uint32_t)ax[k].lo * 4u;
+    off_hi[k] = (uint32_t)ax[k].hi * 4u;
+    off_ex[k] = (uint32_t)ax[k].exact_idx * 4u;
+    all_exact_x = all_exact_x && ax[k].exact;
+  }
+  const bool wave_exact_x = __all(all_exact_x);  // the fovea: every column is an exact hit
+  const char *srcb = reinterpret_cast<const char *>(src);
+  const uint32_t row_bytes = (uint32_t)src_w * 4u;
+  auto texel = [&](uint32_t byte_off) {
+    return *reinterpret_cast<const uint32_t *>(srcb + byte_off);
+  };
+
+  const int y1 = min(y0 + rows, out_h);
+  for (int y = y0; y < y1; ++y) {
+    const InterpAxis ay = interp_axis(y, cyp, ty[y - cyp + range_y], false, out_h, src_h, src_h);
+    uint32_t out[kInterpCols];
+    if (ay.exact && wave_exact_x) {  // :67-72 for the whole wave: plain copies
+#pragma unroll
+      for (int k = 0; k < kInterpCols; ++k)
+        out[k] = texel((uint32_t)ay.exact_idx * row_bytes + off_ex[k]) & 0x00ffffffu;
+    } else {
+      const uint32_t r_lo = (uint32_t)ay.lo * row_bytes, r_hi = (uint32_t)ay.hi * row_bytes;
+      uint32_t tl[kInterpCols], tr[kInterpCols], bl[kInterpCols], br[kInterpCols];
+#pragma unroll
+      for (int k = 0; k < kInterpCols; ++k) {
+        tl[k] = texel(r_lo + off_lo[k]);
+        tr[k] = texel(r_lo + off_hi[k]);
+        bl[k] = texel(r_hi + off_lo[k]);
+        br[k] = texel(r_hi + off_hi[k]);
+      }
+      // two pixels per packed-float instruction (v_pk_mul_f32 / v_pk_add_f32): the same IEEE
+      // operations in the same order as the scalar form, so the results are unchanged
+#pragma unroll
+      for (int k = 0; k < kInterpCols; k += 2) {
+        const f32x2 xr = {ax[k].ratio, ax[k + 1].ratio};
+        const f32x2 yr = {ay.ratio, ay.ratio};
+        uint32_t v0 = 0, v1 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x2 ftl = {(float)((tl[k] >> (8 * c)) & 0xffu), (float)((tl[k + 1] >> (8 * c)) & 0xffu)};
+          const f32x2 fbl = {(float)((bl[k] >> (8 * c)) & 0xffu), (float)((bl[k + 1] >> (8 * c)) & 0xffu)};
+          const f32x2 ftr = {(float)((tr[k] >> (8 * c)) & 0xffu), (float)((tr[k + 1] >> (8 * c)) & 0xffu)};
+          const f32x2 fbr = {(float)((br[k] >> (8 * c)) & 0xffu), (float)((br[k + 1] >> (8 * c)) & 0xffu)};
+          const f32x2 l = ftl + (fbl - ftl) * yr;
+          const f32x2 r = ftr + (fbr - ftr) * yr;
+          const f32x2 m = l + (r - l) * xr;
+          v0 |= ((uint32_t)(int)m.x & 0xffu) << (8 * c);
+          v1 |= ((uint32_t)(int)m.y & 0xffu) << (8 * c);
+        }
+        out[k] = v0;
+        out[k + 1] = v1;
+      }
+#pragma unroll
+      for (int k = 0; k < kInterpCols; ++k)
+        if (ay.exact && ax[k].exact)  // exact hit on both axes -> plain copy
+          out[k] = texel((uint32_t)ay.exact_idx * row_bytes + off_ex[k]) & 0x00ffffffu;
+    }
+    uint32_t *o = dst + (size_t)y * out_w + x_base;
+    if (vec_store && x_base < out_w) {
+      *reinterpret_cast<uint4 *>(o) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kInterpCols; ++k)
+        if (x_base + k < out_w) o[k] = out[k];
     }
   }
-  dst[(size_t)y * out_w + x0] = out;
 }
 
 int upload(f360_ctx *ctx, f360::DevBuf &buf, const void *host, size_t bytes) {
@@ -910,8 +973,8 @@ int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   F360_REQUIRE(target_width >= 2 && target_height >= 2 && source_width >= 1 &&
                    source_height >= 1,
                "f360_satdec_interpolate_rect: bad geometry");
-  F360_REQUIRE(((uintptr_t)target_dev % 4) == 0 && ((uintptr_t)source_dev % 4) == 0,
-               "f360_satdec_interpolate_rect: buffers must be 4-byte aligned");
+  F360_REQUIRE(((uintptr_t)target_dev % 16) == 0 && ((uintptr_t)source_dev % 4) == 0,
+               "f360_satdec_interpolate_rect: target must be 16-byte, source 4-byte aligned");
   F360_REQUIRE(std::fabs(center_x) <= 16.0f && std::fabs(center_y) <= 16.0f,
                "f360_satdec_interpolate_rect: gaze centre out of range");
   const int cxp = (int)(center_x * (float)target_width);
@@ -923,14 +986,16 @@ int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   int st = ensure_interp_tables(dec, target_width, target_height, source_width,
                                 source_height, need_dx, need_dy);
   if (st != F360_OK) return st;
-  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  const int rows = 8;
+  const dim3 grid((target_width + 64 * kInterpCols - 1) / (64 * kInterpCols),
+                  (target_height + 4 * rows - 1) / (4 * rows));
   f360::KernelSpan span(dec->ctx, f360::kInterpolateRect,
                         f360::take_profile_slot(dec->ctx));
   hipLaunchKernelGGL(interpolate_rect_kernel, grid, dim3(256), 0, dec->ctx->stream,
                      reinterpret_cast<uint32_t *>(target_dev), target_width,
                      target_height, reinterpret_cast<const uint32_t *>(source_dev),
                      source_width, source_height, dec->itx_dev.as<int4>(),
-                     dec->it_dx, dec->ity_dev.as<int4>(), dec->it_dy, cxp, cyp);
+                     dec->it_dx, dec->ity_dev.as<int4>(), dec->it_dy, cxp, cyp, rows);
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

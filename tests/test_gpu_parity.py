@@ -540,7 +540,7 @@ def test_send_frame_loop_example(f360, gpu_ctx, oracle, tmp_path):
 
 # --------------------------------------------------------------------- odd geometries / threads
 @pytest.mark.parametrize("w,h,rw,rh", [(64, 32, 16, 16), (200, 120, 33, 77), (512, 96, 300, 20),
-                                       (1280, 720, 720, 400), (48, 48, 64, 64)])
+                                       (1280, 720, 720, 400), (48, 48, 64, 64), (250, 101, 61, 45)])
 def test_sampler_variants_on_odd_geometries(f360, gpu_ctx, oracle, w, h, rw, rh):
     """Reduced sizes that do not follow the 1.8 rule, fewer columns than one wave, targets larger
     than the source: every sampler variant (the streaming ones fall back when they do not apply)
