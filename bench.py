@@ -88,6 +88,11 @@ def main():
                     help="sample every n-th frame with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="key=value engine option")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; 'gloo' only to rehearse the N>1 launch path "
+                         "on a box with fewer GPUs than ranks (see --share-device)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (invalid as a measurement)")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,10 +111,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no HIP device visible; this benchmark has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     import f360_amd as f360  # after torch: share torch's HIP runtime
     w, h = args.width, args.height
@@ -171,7 +181,8 @@ def main():
     # the only collective of the run: RCCL max of the timing / sum of the pixels
     from importlib import import_module
     sharding = import_module("foveated-360-video_amd.sharding")
-    elapsed, total_px = sharding.reduce_run(elapsed, float(args.steps) * B * w * h, device=dev)
+    elapsed, total_px = sharding.reduce_run(elapsed, float(args.steps) * B * w * h,
+                                            device=dev if args.backend == "nccl" else None)
 
     # ---- per-kernel times of the sampled frames (HIP events on the launch stream) --------
     prof = {}
@@ -219,7 +230,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.share_device else "synthetic (REHEARSAL: ranks share GPU 0)",
             "config": {"workload": f"{w}x{h} RGB0 equirect frames, SAT encode -> log-rectilinear "
                                    f"SAT sample to {rw}x{rh}, batch {B} frames per GPU per step, "
                                    f"Lissajous gaze, inputs resident in HBM",
