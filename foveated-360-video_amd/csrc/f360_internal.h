@@ -94,6 +94,7 @@ struct f360_ctx {
   int opt_sample_variant = 1;  // "sample.variant": 0 per-pixel, 1 column walker, 2 row streaming, 3 hybrid
   int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
+  int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)

@@ -245,6 +245,7 @@ static const OptionSlot kOptions[] = {
     {"sample.variant", &f360_ctx::opt_sample_variant},
     {"sample.rows", &f360_ctx::opt_walk_rows},
     {"debug.ablate", &f360_ctx::opt_ablate},
+    {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
 };
 

@@ -986,7 +986,11 @@ int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   int st = ensure_interp_tables(dec, target_width, target_height, source_width,
                                 source_height, need_dx, need_dy);
   if (st != F360_OK) return st;
-  const int rows = 8;
+  // rows per wave: enough to amortise the per-column set-up on large frames, few enough
+  // that a small frame still yields thousands of waves (each row is a chain of dependent loads)
+  const long px = (long)target_width * target_height;
+  const int rows = dec->ctx->opt_interp_rows > 0 ? dec->ctx->opt_interp_rows
+                   : px >= 16000000 ? 16 : px >= 6000000 ? 4 : 1;
   const dim3 grid((target_width + 64 * kInterpCols - 1) / (64 * kInterpCols),
                   (target_height + 4 * rows - 1) / (4 * rows));
   f360::KernelSpan span(dec->ctx, f360::kInterpolateRect,
