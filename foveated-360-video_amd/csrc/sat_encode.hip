@@ -446,15 +446,23 @@ int ensure_plan(f360_ctx *ctx, int width, int height) {
         break;
       }
   }
+  // bands per reducer wave: at least 2, and few enough super-bands (<= 32) that the carry
+  // kernel needs a single round of loads
+  int sb_bands = ctx->opt_sb_bands;
+  if (sb_bands == 0) {
+    const int nb = (height + band_rows - 1) / band_rows;
+    sb_bands = (nb + 31) / 32;
+    if (sb_bands < 2) sb_bands = 2;
+  }
   if (p.width == width && p.height == height && p.band_rows == band_rows &&
-      p.sb_bands == ctx->opt_sb_bands && p.ws.p)
+      p.sb_bands == sb_bands && p.ws.p)
     return F360_OK;
   // A geometry change re-carves the scratch; wait for work that may use it.
   if (p.ws.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
   p.width = width;
   p.height = height;
   p.band_rows = band_rows;
-  p.sb_bands = ctx->opt_sb_bands;
+  p.sb_bands = sb_bands;
   p.nstrips = (width + kStripPx - 1) / kStripPx;
   p.nbands = (height + p.band_rows - 1) / p.band_rows;
   p.nsb = (p.nbands + p.sb_bands - 1) / p.sb_bands;
