@@ -94,6 +94,8 @@ _SIGNATURES = {
                                         c_int, c_int, c_float, c_float]),
     "f360_satdec_sample_rect_batch": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                               c_int, c_void_p, c_int, c_int, POINTER(c_float)]),
+    "f360_satdec_foveate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                         c_int, c_int, c_float, c_float]),
     "f360_satdec_interpolate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_void_p, c_int, c_int, c_int, c_float,
                                              c_float]),
@@ -362,6 +364,17 @@ class SATDecoder:
         _check(lib().f360_satdec_sample_rect_batch(self._h, ptrs, n, target_width,
                                                    target_height, target_linesize,
                                                    _p(cl_source_buffer), w, h, xy))
+
+    def FoveateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
+                            target_linesize, cl_source_frame, source_width, source_height,
+                            source_linesize, center_x, center_y) -> None:
+        """EncodeFrameGPU + SampleFrameRectGPU in one pass for a gaze known up front
+        (SURVEY.md 8f-1): same bytes, no table written or re-read."""
+        self._need("FoveateFrameRectGPU")
+        _check(lib().f360_satdec_foveate_rect(self._h, _p(cl_target_buffer), target_width,
+                                              target_height, target_linesize,
+                                              _p(cl_source_frame), source_width, source_height,
+                                              source_linesize, center_x, center_y))
 
     def InterpolateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
                                 target_linesize, cl_source_buffer, source_width,

@@ -74,6 +74,8 @@ enum KernelId {
   kIsInterpolateLogpolar,
   kIsBlur,
   kGnomonic,
+  kFovMaps,
+  kFovSample,
   kKernelCount
 };
 struct ProfSpan {
@@ -146,6 +148,17 @@ inline bool take_profile_slot(f360_ctx *ctx) {
 }
 }  // namespace f360
 
+namespace f360 {
+// Fused foveation: what the table writer emits instead of the full table.
+struct SatEmit {
+  const int *xmap, *ymap;
+  uint32_t *corners;
+  int corner_stride;
+};
+int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
+                    int height, int linesize, const SatEmit *emit);
+}  // namespace f360
+
 struct f360_event {
   hipEvent_t ev = nullptr;
 };
@@ -162,6 +175,8 @@ struct f360_sat_decoder {
   bool stream_ok = false;
   int dense_begin = 0, dense_end = 0;  // reduced columns with unit corner steps (fovea)
   int hybrid_passes = 0;               // 0: hybrid sampler not applicable
+  // fused foveation (f360_satdec_foveate_rect): per-gaze lattice maps and the compact corners
+  f360::DevBuf fov_maps, fov_corners;
   // inverse-map tables of the interpolate kernel, indexed by pixel offset from
   // the gaze centre (geometry-only; see sat_decoder.hip)
   int it_w = 0, it_h = 0, it_rw = 0, it_rh = 0;  // geometry they were built for

@@ -283,7 +283,8 @@ static const char *const kKernelNames[f360::kKernelCount] = {
     "sat_reduce_kernel",        "sat_carry_kernel",       "sat_write_kernel",
     "sample_rect_kernel",       "interpolate_rect_kernel", "decode_kernel",
     "is_sample_rect_kernel",    "is_sample_logpolar_kernel",
-    "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel"};
+    "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel",
+    "foveate_maps_kernel",      "sample_compact_kernel"};
 
 int f360_kernel_count(void) { return f360::kKernelCount; }
 

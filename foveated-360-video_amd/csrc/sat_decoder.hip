@@ -476,6 +476,148 @@ __global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArg
 }
 
 // ---------------------------------------------------------------------------
+// Fused foveation (SURVEY.md 8f-1 i): frame -> reduced frame without materialising the table.
+// When the gaze is known before the encode (the offline modes of the reference take it from a
+// trace, run_satlogrectilinear.cc:926-938), only the table entries at the lattice rows / columns
+// that gaze samples are ever read.  foveate_maps_kernel numbers those rows and columns, the table
+// writer (sat_encode.hip, STORE == 2) emits just those entries into a compact array, and
+// sample_compact_kernel forms the box means from it -- the same integers as encode + sample.
+struct FovMaps {
+  const int16_t *gx, *gy;
+  int cxp, cyp, src_w, src_h, out_w, out_h;
+  int *xmap, *ymap;          // source column / row -> compact index or -1
+  int *ihx, *ilx, *dxw;      // per reduced column: compact index of hi / lo corner, box width
+  int *ihy, *ily, *dyw;      // per reduced row
+};
+
+constexpr int kFovLdsEntries = 16384;  // axis lengths up to this are ranked in LDS
+
+__global__ __launch_bounds__(1024) void foveate_maps_kernel(const FovMaps m) {
+  __shared__ int part[1024];
+  __shared__ int lflag[kFovLdsEntries];
+  const bool is_x = blockIdx.x == 0;
+  const int size = is_x ? m.src_w : m.src_h, n_out = is_x ? m.out_w : m.out_h;
+  const int16_t *g = is_x ? m.gx : m.gy;
+  const int centre = is_x ? m.cxp : m.cyp;
+  int *map = is_x ? m.xmap : m.ymap;
+  int *ih = is_x ? m.ihx : m.ihy, *il = is_x ? m.ilx : m.ily, *dw = is_x ? m.dxw : m.dyw;
+  int *flag = size <= kFovLdsEntries ? lflag : map;  // LDS when it fits, else in place
+  const int t = threadIdx.x;
+  for (int x = t; x < size; x += 1024) flag[x] = 0;
+  __syncthreads();
+  for (int i = t; i < n_out; i += 1024) {
+    const AxisBox b = sample_axis(centre, g[i + 1], g[i], size, is_x);
+    if (b.ok) {
+      flag[b.hi] = 1;
+      flag[b.lo] = 1;
+    }
+  }
+  __syncthreads();
+  // rank the used entries: per-thread chunk counts, block scan, then the ranks
+  const int chunk = (size + 1023) / 1024;
+  const int a = min(t * chunk, size), e = min(a + chunk, size);
+  int cnt = 0;
+  for (int x = a; x < e; ++x) cnt += flag[x];
+  part[t] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - cnt;
+  for (int x = a; x < e; ++x) {
+    const int f = flag[x];
+    const int rank = f ? run : -1;
+    flag[x] = rank;
+    if (flag != map) map[x] = rank;
+    run += f;
+  }
+  __syncthreads();
+  for (int i = t; i < n_out; i += 1024) {
+    const AxisBox b = sample_axis(centre, g[i + 1], g[i], size, is_x);
+    ih[i] = b.ok ? flag[b.hi] : -1;
+    il[i] = b.ok ? flag[b.lo] : -1;
+    dw[i] = b.hi - b.lo;
+  }
+}
+
+// The walker on the compact corner array: a box is (ih, il) in compact indices instead of
+// table coordinates; the sharing tests between neighbouring lanes / rows are the same.
+__global__ __launch_bounds__(256) void sample_compact_walk_kernel(
+    uint8_t *__restrict__ dst, int out_w, int out_h, int out_stride_px,
+    const uint32_t *__restrict__ corners, int corner_stride, const int *__restrict__ ihx,
+    const int *__restrict__ ilx, const int *__restrict__ dxw, const int *__restrict__ ihy,
+    const int *__restrict__ ily, const int *__restrict__ dyw, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int c0 = __builtin_amdgcn_readfirstlane(
+      ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kWalkCols);
+  if (c0 >= out_w) return;  // whole wave
+  const int i = c0 - 1 + lane;
+  const int ic = min(max(i, 0), out_w - 1);
+  const int hx = ihx[ic], lx = ilx[ic];
+  const bool writes = lane > 0 && i < out_w && hx >= 0;
+  const uint32_t x_hi = (uint32_t)max(hx, 0) * 12u, x_lo = (uint32_t)max(lx, 0) * 12u;
+  const bool left_shared = lane == 0 || dpp_from_lane_below(x_hi) == x_lo;
+  const uint32_t dx = (uint32_t)dxw[ic];
+  const uint32_t row_bytes = (uint32_t)corner_stride * 12u;
+  uint8_t *out = dst + (size_t)i * 4;
+  const int j0 = (int)blockIdx.y * rows, j1 = min(j0 + rows, out_h);
+
+  int prev_hi = -1;
+  uint3 p_br = make_uint3(0, 0, 0), p_bl = make_uint3(0, 0, 0);
+  for (int jb = j0; jb < j1; jb += kWalkBatch) {
+    int hy[kWalkBatch], ly[kWalkBatch];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < kWalkBatch; ++r) {
+      const int j = min(jb + r, out_h - 1);
+      hy[r] = (jb + r < j1) ? ihy[j] : -1;  // wave-uniform
+      ly[r] = ily[j];
+      any = any || hy[r] >= 0;
+    }
+    if (!any) {
+      prev_hi = -1;
+      continue;
+    }
+    uint3 brs[kWalkBatch];
+#pragma unroll
+    for (int r = 0; r < kWalkBatch; ++r)
+      brs[r] = load_sat3_at(corners, (uint32_t)max(hy[r], 0) * row_bytes + x_hi);
+#pragma unroll
+    for (int r = 0; r < kWalkBatch; ++r) {
+      if (hy[r] < 0) {
+        prev_hi = -1;
+        continue;
+      }
+      const uint3 br = brs[r];
+      uint3 bl = dpp_from_lane_below(br);
+      if (!left_shared) bl = load_sat3_at(corners, (uint32_t)hy[r] * row_bytes + x_lo);
+      uint3 tr, tl;
+      if (ly[r] == prev_hi) {
+        tr = p_br;
+        tl = p_bl;
+      } else {
+        tr = load_sat3_at(corners, (uint32_t)ly[r] * row_bytes + x_hi);
+        tl = dpp_from_lane_below(tr);
+        if (!left_shared) tl = load_sat3_at(corners, (uint32_t)ly[r] * row_bytes + x_lo);
+      }
+      if (writes) {
+        const int j = min(jb + r, out_h - 1);
+        const uint3 q = udiv3_exact(make_uint3(br.x - tr.x + tl.x - bl.x, br.y - tr.y + tl.y - bl.y,
+                                               br.z - tr.z + tl.z - bl.z),
+                                    dx * (uint32_t)dyw[j]);
+        store_rgb(out + (size_t)j * ((size_t)out_stride_px * 4), q.x, q.y, q.z);
+      }
+      p_br = br;
+      p_bl = bl;
+      prev_hi = hy[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // decode_kernel (src/sat_decoder_decode_kernel.cl:1-58): 1x1 boxes.
 __global__ __launch_bounds__(256) void decode_kernel(
     uint8_t *__restrict__ dst, int dst_linesize, int dst_bpp,
@@ -692,6 +834,8 @@ int f360_satdec_destroy(f360_sat_decoder *dec) {
   dec->itx_dev.release();
   dec->ity_dev.release();
   dec->lbx_dev.release();
+  dec->fov_maps.release();
+  dec->fov_corners.release();
   delete dec;
   return F360_OK;
 }
@@ -941,6 +1085,83 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
   f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
   hipLaunchKernelGGL(sample_rect_walk_batch_kernel, grid, dim3(256), 0, ctx->stream, sa, b,
                      rows);
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+int f360_satdec_foveate_rect(f360_sat_decoder *dec, uint8_t *target_dev, int target_width,
+                             int target_height, int target_linesize,
+                             const uint8_t *source_dev, int source_width, int source_height,
+                             int source_linesize, float center_x, float center_y) {
+  F360_REQUIRE(dec, "f360_satdec_foveate_rect: null decoder");
+  F360_REQUIRE(target_dev && source_dev, "f360_satdec_foveate_rect: null buffer");
+  F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
+                   source_height >= 2 && target_linesize >= 4 * target_width,
+               "f360_satdec_foveate_rect: bad geometry");
+  F360_REQUIRE(std::fabs(center_x) <= 16.0f && std::fabs(center_y) <= 16.0f,
+               "f360_satdec_foveate_rect: gaze centre out of range");
+  if (!dec->gx_dev.p) {
+    int st = f360_satdec_initialize_grid(dec, target_width, target_height, source_width,
+                                         source_height);
+    if (st != F360_OK) return st;
+  }
+  F360_REQUIRE(dec->gw == target_width && dec->gh == target_height,
+               "f360_satdec_foveate_rect: grid was initialised for %dx%d", dec->gw, dec->gh);
+  f360_ctx *ctx = dec->ctx;
+  F360_HIP_TRY(hipSetDevice(ctx->device));
+  // compact corner array: at most two distinct corners per reduced column / row
+  const int cap_x = std::min(2 * target_width + 2, source_width);
+  const int cap_y = std::min(2 * target_height + 2, source_height);
+  F360_REQUIRE((size_t)cap_x * cap_y * 12 < ((size_t)1 << 32),
+               "f360_satdec_foveate_rect: frame too large");
+  const size_t n_maps = (size_t)source_width + source_height + 3 * (size_t)target_width +
+                        3 * (size_t)target_height;
+  if (dec->fov_maps.bytes < n_maps * sizeof(int) ||
+      dec->fov_corners.bytes < (size_t)cap_x * cap_y * 12) {
+    F360_HIP_TRY(hipStreamSynchronize(ctx->stream));  // earlier calls may still use the old ones
+    int st = dec->fov_maps.reserve(n_maps * sizeof(int));
+    if (st != F360_OK) return st;
+    st = dec->fov_corners.reserve((size_t)cap_x * cap_y * 12);
+    if (st != F360_OK) return st;
+  }
+  FovMaps m;
+  m.gx = dec->gx_dev.as<int16_t>();
+  m.gy = dec->gy_dev.as<int16_t>();
+  m.cxp = (int)(center_x * (float)source_width);
+  m.cyp = (int)(center_y * (float)source_height);
+  m.src_w = source_width;
+  m.src_h = source_height;
+  m.out_w = target_width;
+  m.out_h = target_height;
+  int *w = dec->fov_maps.as<int>();
+  m.xmap = w;  w += source_width;
+  m.ymap = w;  w += source_height;
+  m.ihx = w;   w += target_width;
+  m.ilx = w;   w += target_width;
+  m.dxw = w;   w += target_width;
+  m.ihy = w;   w += target_height;
+  m.ily = w;   w += target_height;
+  m.dyw = w;
+  const bool prof = f360::take_profile_slot(ctx);
+  {
+    f360::KernelSpan span(ctx, f360::kFovMaps, prof);
+    hipLaunchKernelGGL(foveate_maps_kernel, dim3(2), dim3(1024), 0, ctx->stream, m);
+  }
+  if (prof) ctx->prof_armed += 1;  // the encode below belongs to the same sampled call
+  f360::SatEmit emit{m.xmap, m.ymap, dec->fov_corners.as<uint32_t>(), cap_x};
+  int st = f360::sat_encode_impl(ctx, nullptr, source_dev, source_width, source_height,
+                                 source_linesize, &emit);
+  if (st != F360_OK) return st;
+  {
+    f360::KernelSpan span(ctx, f360::kFovSample, prof);
+    const int rows = ctx->opt_walk_rows;
+    const dim3 grid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),
+                    (target_height + rows - 1) / rows);
+    hipLaunchKernelGGL(sample_compact_walk_kernel, grid, dim3(256), 0, ctx->stream, target_dev,
+                       target_width, target_height, target_linesize / 4,
+                       dec->fov_corners.as<uint32_t>(), cap_x, m.ihx, m.ilx, m.dxw, m.ihy,
+                       m.ily, m.dyw, rows);
+  }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

@@ -49,6 +49,9 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) u32x3 {
+  uint32_t x, y, z;
+};
 
 // LDS byte address in, 16 bytes per lane.  The reads carry their own wait
 // (hipcc does not count memory operations issued from inline asm).
@@ -75,6 +78,11 @@ struct EncodeArgs {
   uint32_t *lp, *sbtotal, *sbprefix, *rowsum, *rowcarry, *tiletotal, *tprefix;
   int reverse;
   int ablate;  // timing experiments only (results are wrong when non-zero)
+  // STORE == 2 (fused foveation): instead of the table, emit only the entries at the
+  // lattice rows / columns a given gaze will sample
+  const int *xmap, *ymap;  // source column / row -> compact index, -1 when unused
+  uint32_t *corners;       // [compact row][corner_stride][3]
+  int corner_stride;
 };
 
 // Four pixels of one row as packed R | G<<8 | B<<16 dwords (0 beyond the row).
@@ -331,6 +339,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   if (strip >= a.nstrips) return;
   const int x0 = strip * kStripPx + lane * kLanePx;
   const int sb = band / a.sb_bands;
+  int xm[4] = {-1, -1, -1, -1};
+  if (STORE == 2) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (x0 + k < a.width) xm[k] = a.xmap[x0 + k];
+  }
 
   // --- table row just above the band, for this lane's 4 pixels -------------
   uint32_t acc[12];
@@ -395,6 +409,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
         acc[3 * k + 0] += c[3 * k + 0] + base_r;
         acc[3 * k + 1] += c[3 * k + 1] + base_g;
         acc[3 * k + 2] += c[3 * k + 2] + base_b;
+      }
+      if (STORE == 2) {
+        const int py = a.ymap[y + r];  // wave-uniform
+        if (py >= 0) {
+          uint32_t *crow = a.corners + (size_t)py * a.corner_stride * 3;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (xm[k] >= 0) {  // one 12-byte store per lattice texel
+              u32x3 v = {acc[3 * k + 0], acc[3 * k + 1], acc[3 * k + 2]};
+              *reinterpret_cast<u32x3 *>(crow + (size_t)xm[k] * 3) = v;
+            }
+        }
+        continue;
       }
       uint32_t *row = a.sat + (size_t)(y + r) * a.width * 3;
       if (VEC && STORE == 0) {
@@ -499,11 +526,12 @@ extern "C" int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height) {
   return ensure_plan(ctx, width, height);
 }
 
-extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
-                               const uint8_t *src_dev, int width, int height,
-                               int linesize) {
+namespace f360 {
+
+int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
+                    int height, int linesize, const SatEmit *emit) {
   F360_REQUIRE(ctx, "f360_sat_encode: null context");
-  F360_REQUIRE(sat_dev && src_dev, "f360_sat_encode: null buffer");
+  F360_REQUIRE((sat_dev || emit) && src_dev, "f360_sat_encode: null buffer");
   F360_REQUIRE(width >= 1 && height >= 1, "f360_sat_encode: bad size %dx%d", width,
                height);
   const int bpp = linesize / width;  // src/sat_encoder_encode_kernels.cl:9
@@ -537,10 +565,15 @@ extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
   a.tprefix = p.tprefix;
   a.reverse = ctx->opt_reverse_tiles;
   a.ablate = ctx->opt_ablate;
+  a.xmap = emit ? emit->xmap : nullptr;
+  a.ymap = emit ? emit->ymap : nullptr;
+  a.corners = emit ? emit->corners : nullptr;
+  a.corner_stride = emit ? emit->corner_stride : 0;
 
   const bool prof = f360::take_profile_slot(ctx);
   const bool vec = bpp == 4 && (width % 4) == 0 && (linesize % 16) == 0 &&
-                   ((uintptr_t)src_dev % 16) == 0 && ((uintptr_t)sat_dev % 16) == 0;
+                   ((uintptr_t)src_dev % 16) == 0 &&
+                   (emit || ((uintptr_t)sat_dev % 16) == 0);
   const dim3 block(64 * kWavesPerBlock);
   const int bx = (p.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
 
@@ -567,7 +600,11 @@ extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
   {
     f360::KernelSpan span(ctx, f360::kSatWrite, prof);
     const dim3 grid3(bx, p.nbands);
-    if (!vec)
+    if (emit && vec)
+      hipLaunchKernelGGL((sat_write_kernel<true, 2>), grid3, block, 0, ctx->stream, a);
+    else if (emit)
+      hipLaunchKernelGGL((sat_write_kernel<false, 2>), grid3, block, 0, ctx->stream, a);
+    else if (!vec)
       hipLaunchKernelGGL((sat_write_kernel<false, 0>), grid3, block, 0, ctx->stream, a);
     else if (ctx->opt_store_mode == 1)
       hipLaunchKernelGGL((sat_write_kernel<true, 1>), grid3, block, 0, ctx->stream, a);
@@ -576,4 +613,12 @@ extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev,
   }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
+}
+
+}  // namespace f360
+
+extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev,
+                               int width, int height, int linesize) {
+  F360_REQUIRE(sat_dev, "f360_sat_encode: null buffer");
+  return f360::sat_encode_impl(ctx, sat_dev, src_dev, width, height, linesize, nullptr);
 }

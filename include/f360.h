@@ -137,6 +137,16 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec,
                                   int target_linesize, const uint32_t *sat_dev,
                                   int source_width, int source_height,
                                   const float *centers_xy);
+/* Fused SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for a gaze that
+ * is known before the encode (the reference's offline modes read it from a trace,
+ * src/run_satlogrectilinear.cc:926-938): frame -> reduced frame, the same bytes as
+ * the two calls, without writing or re-reading the table.
+ * Not in the reference.  Target semantics are f360_satdec_sample_rect's. */
+int f360_satdec_foveate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
+                             int target_width, int target_height,
+                             int target_linesize, const uint8_t *source_dev,
+                             int source_width, int source_height,
+                             int source_linesize, float center_x, float center_y);
 /* SATDecoder::InterpolateFrameRectGPU (src/sat_decoder.h:77-82,
  * src/sat_decoder.cc:887-928; interpolate_rect_kernel
  * src/sat_decoder_interpolate_kernel.cl:1-152).  Like the reference kernel the

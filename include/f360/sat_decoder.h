@@ -77,6 +77,25 @@ class SATDecoder {
                 << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 
+  // Not in the reference: EncodeFrameGPU + SampleFrameRectGPU fused for a gaze known before the
+  // encode (its offline modes, src/run_satlogrectilinear.cc:926-938); same bytes, no table.
+  void FoveateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
+                           int target_linesize, cl_mem cl_source_frame, int source_width,
+                           int source_height, int source_linesize, float center_x,
+                           float center_y) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::FoveateFrameRectGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_foveate_rect(
+        impl, static_cast<uint8_t *>(cl_target_buffer), target_width, target_height,
+        target_linesize, static_cast<const uint8_t *>(cl_source_frame), source_width,
+        source_height, source_linesize, center_x, center_y);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::FoveateFrameRectGPU] kernel launch failed:" << ret << " "
+                << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
   // src/sat_decoder.cc:887-928
   void InterpolateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
                                int target_linesize, cl_mem cl_source_buffer, int source_width,

@@ -643,3 +643,28 @@ def test_encode_sample_inside_a_hip_graph(f360, oracle):
     assert np.array_equal(red.cpu().numpy(), want_red)
     dec.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h,bpp,rw,rh", [(64, 32, 4, 0, 0), (256, 128, 4, 0, 0), (1920, 1080, 4, 0, 0),
+                                           (640, 360, 3, 0, 0), (250, 101, 4, 61, 45), (3840, 1920, 4, 0, 0)])
+def test_fused_foveation_equals_encode_then_sample(f360, gpu_ctx, oracle, w, h, bpp, rw, rh):
+    """8(f)-1: frame -> reduced frame in one pass (no table written) gives the bytes of
+    EncodeFrameGPU + SampleFrameRectGPU, i.e. of the oracle's encode + sample."""
+    rw, rh = rw or reduced(w), rh or reduced(h)
+    frame = oracle.lcg_frame(w, h, 606, bpp=bpp)
+    sat_h = oracle.sat_encode(frame, w, h, bpp * w)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    dec = f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    src = gpu_ctx.upload(frame)
+    dst = gpu_ctx.malloc(rh * (4 * rw + 16))
+    gazes = GAZES + EXTRA_GAZES if w <= 1920 else GAZES[1:3]
+    for (cx, cy) in gazes:
+        want = np.full((rh, 4 * rw + 16), 0xA5, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, 4 * rw + 16, sat_h, w, h, grid, cx, cy)
+        dst.fill(0xA5)
+        dec.FoveateFrameRectGPU(dst.ptr, rw, rh, 4 * rw + 16, src.ptr, w, h, bpp * w, cx, cy)
+        assert np.array_equal(dst.copy_to_host(np.uint8, (rh, 4 * rw + 16)), want), (cx, cy)
+    src.free()
+    dst.free()
+    dec.close()
