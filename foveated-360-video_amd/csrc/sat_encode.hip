@@ -234,10 +234,14 @@ template <bool VEC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
     const EncodeArgs a) {
   const int lane = threadIdx.x & 63;
-  const int strip = __builtin_amdgcn_readfirstlane(
+  // 1-D grid over the tiles in row-major order, 4 consecutive tiles per workgroup: every
+  // workgroup is full, so the round-robin of workgroups over the 8 XCDs stays balanced (a 2-D
+  // grid with 8 workgroup columns pins each strip group to one XCD, the ragged last one too)
+  const int tile = __builtin_amdgcn_readfirstlane(
       (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
-  const int sb = blockIdx.y;
-  if (strip >= a.nstrips) return;
+  if (tile >= a.nstrips * a.nsb) return;
+  const int sb = tile / a.nstrips;
+  const int strip = tile - sb * a.nstrips;
   const int x0 = strip * kStripPx + lane * kLanePx;
 
   ReduceState st;
@@ -329,14 +333,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
       stage[STORE == 1 ? kWavesPerBlock * 3 * kStripPx : 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  int bx = blockIdx.x, band = blockIdx.y;
-  if (a.reverse) {
-    bx = (int)gridDim.x - 1 - bx;
-    band = (int)gridDim.y - 1 - band;
-  }
-  const int strip =
-      __builtin_amdgcn_readfirstlane(bx * kWavesPerBlock + wave);
-  if (strip >= a.nstrips) return;
+  int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kWavesPerBlock + wave);
+  if (tile >= a.nstrips * a.nbands) return;  // 1-D grid over the tiles, see sat_reduce_kernel
+  if (a.reverse) tile = a.nstrips * a.nbands - 1 - tile;
+  const int band = tile / a.nstrips;
+  const int strip = tile - band * a.nstrips;
   const int x0 = strip * kStripPx + lane * kLanePx;
   const int sb = band / a.sb_bands;
   int xm[4] = {-1, -1, -1, -1};
@@ -575,16 +576,14 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                    ((uintptr_t)src_dev % 16) == 0 &&
                    (emit || ((uintptr_t)sat_dev % 16) == 0);
   const dim3 block(64 * kWavesPerBlock);
-  const int bx = (p.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int blocks1 = (p.nstrips * p.nsb + kWavesPerBlock - 1) / kWavesPerBlock;
 
   {
     f360::KernelSpan span(ctx, f360::kSatReduce, prof);
     if (vec)
-      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(bx, p.nsb), block, 0, ctx->stream,
-                         a);
+      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(blocks1), block, 0, ctx->stream, a);
     else
-      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(bx, p.nsb), block, 0,
-                         ctx->stream, a);
+      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(blocks1), block, 0, ctx->stream, a);
   }
 
   ScanSeg sa{p.sbtotal, p.sbprefix, p.wp3, p.nsb, (p.wp3 + 255) / 256};
@@ -599,7 +598,7 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   }
   {
     f360::KernelSpan span(ctx, f360::kSatWrite, prof);
-    const dim3 grid3(bx, p.nbands);
+    const dim3 grid3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock);
     if (emit && vec)
       hipLaunchKernelGGL((sat_write_kernel<true, 2>), grid3, block, 0, ctx->stream, a);
     else if (emit)
