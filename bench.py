@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--height", type=int, default=3840)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="contexts (in-order streams) per GPU")
-    ap.add_argument("--profile-every", type=int, default=8,
+    ap.add_argument("--profile-every", type=int, default=16,
                     help="sample every n-th frame with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="key=value engine option")

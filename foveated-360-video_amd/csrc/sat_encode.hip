@@ -49,6 +49,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16 B
 struct __attribute__((packed, aligned(4))) u32x3 {
   uint32_t x, y, z;
 };
@@ -330,7 +331,7 @@ template <bool VEC, int STORE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
     const EncodeArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t
-      stage[STORE == 1 ? kWavesPerBlock * 3 * kStripPx : 4];
+      stage[STORE >= 1 ? kWavesPerBlock * 3 * kStripPx : 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kWavesPerBlock + wave);
@@ -341,10 +342,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   const int x0 = strip * kStripPx + lane * kLanePx;
   const int sb = band / a.sb_bands;
   int xm[4] = {-1, -1, -1, -1};
+  bool dense = false;  // every pixel of the wave is a lattice column, ranks consecutive
+  int xm_first = 0;
   if (STORE == 2) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (x0 + k < a.width) xm[k] = a.xmap[x0 + k];
+    xm_first = __builtin_amdgcn_readfirstlane(xm[0]);
+    dense = __all(xm[0] == xm_first + 4 * lane && xm[1] == xm[0] + 1 && xm[2] == xm[0] + 2 &&
+                  xm[3] == xm[0] + 3 && xm_first >= 0);
   }
 
   // --- table row just above the band, for this lane's 4 pixels -------------
@@ -415,12 +421,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
         const int py = a.ymap[y + r];  // wave-uniform
         if (py >= 0) {
           uint32_t *crow = a.corners + (size_t)py * a.corner_stride * 3;
+          if (dense) {
+            // the wave's 768 dwords are contiguous in the compact row: re-stage through LDS as
+            // the table writer does and store 1 KiB per instruction (4-byte aligned only)
+            const uint32_t mine =
+                (uint32_t)reinterpret_cast<uintptr_t>(stage) + wave * 3 * kStripPx * 4;
+            lds_write_b128(mine + lane * 48, u32x4{acc[0], acc[1], acc[2], acc[3]});
+            lds_write_b128(mine + lane * 48 + 16, u32x4{acc[4], acc[5], acc[6], acc[7]});
+            lds_write_b128(mine + lane * 48 + 32, u32x4{acc[8], acc[9], acc[10], acc[11]});
+            u32x4 v[3];
+            lds_read3_b128(mine + lane * 16, v[0], v[1], v[2]);
+            uint32_t *dst = crow + (size_t)xm_first * 3;
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (xm[k] >= 0) {  // one 12-byte store per lattice texel
-              u32x3 v = {acc[3 * k + 0], acc[3 * k + 1], acc[3 * k + 2]};
-              *reinterpret_cast<u32x3 *>(crow + (size_t)xm[k] * 3) = v;
-            }
+            for (int q = 0; q < 3; ++q)
+              *reinterpret_cast<u32x4_a4 *>(dst + q * 256 + lane * 4) = v[q];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (xm[k] >= 0) {  // one 12-byte store per lattice texel
+                u32x3 v = {acc[3 * k + 0], acc[3 * k + 1], acc[3 * k + 2]};
+                *reinterpret_cast<u32x3 *>(crow + (size_t)xm[k] * 3) = v;
+              }
+          }
         }
         continue;
       }
