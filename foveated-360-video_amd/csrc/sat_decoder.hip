@@ -196,6 +196,18 @@ __device__ __forceinline__ void walk_body(const SampleArgs &a, int c0, int col_b
 #pragma unroll
     for (int r = 0; r < kWalkBatch; ++r)  // clamped corners are always in range
       brs[r] = load_sat3_at(sat, (uint32_t)by[r].hi * row_bytes + x_hi);
+    // the top row of the batch's first box, when the previous batch does not provide it: issued
+    // with the batch's gathers instead of costing a round trip of its own later
+    int first = kWalkBatch, top_row = 0;
+#pragma unroll
+    for (int r = kWalkBatch - 1; r >= 0; --r)
+      if (by[r].ok) {
+        first = r;
+        top_row = by[r].lo;
+      }
+    const bool have_top = top_row != prev_hi;
+    uint3 top = make_uint3(0, 0, 0);
+    if (have_top) top = load_sat3_at(sat, (uint32_t)top_row * row_bytes + x_hi);
 #pragma unroll
     for (int r = 0; r < kWalkBatch; ++r) {
       if (!by[r].ok) {
@@ -210,7 +222,9 @@ __device__ __forceinline__ void walk_body(const SampleArgs &a, int c0, int col_b
         tr = p_br;
         tl = p_bl;
       } else {
-        tr = load_sat3_at(sat, (uint32_t)by[r].lo * row_bytes + x_hi);
+        tr = (have_top && r == first)
+                 ? top
+                 : load_sat3_at(sat, (uint32_t)by[r].lo * row_bytes + x_hi);
         tl = dpp_from_lane_below(tr);
         if (!left_shared) tl = load_sat3_at(sat, (uint32_t)by[r].lo * row_bytes + x_lo);
       }
@@ -585,6 +599,16 @@ __global__ __launch_bounds__(256) void sample_compact_walk_kernel(
 #pragma unroll
     for (int r = 0; r < kWalkBatch; ++r)
       brs[r] = load_sat3_at(corners, (uint32_t)max(hy[r], 0) * row_bytes + x_hi);
+    int first = kWalkBatch, top_row = 0;  // top row of the batch's first box, see walk_body
+#pragma unroll
+    for (int r = kWalkBatch - 1; r >= 0; --r)
+      if (hy[r] >= 0) {
+        first = r;
+        top_row = ly[r];
+      }
+    const bool have_top = top_row != prev_hi;
+    uint3 top = make_uint3(0, 0, 0);
+    if (have_top) top = load_sat3_at(corners, (uint32_t)top_row * row_bytes + x_hi);
 #pragma unroll
     for (int r = 0; r < kWalkBatch; ++r) {
       if (hy[r] < 0) {
@@ -599,7 +623,9 @@ __global__ __launch_bounds__(256) void sample_compact_walk_kernel(
         tr = p_br;
         tl = p_bl;
       } else {
-        tr = load_sat3_at(corners, (uint32_t)ly[r] * row_bytes + x_hi);
+        tr = (have_top && r == first)
+                 ? top
+                 : load_sat3_at(corners, (uint32_t)ly[r] * row_bytes + x_hi);
         tl = dpp_from_lane_below(tr);
         if (!left_shared) tl = load_sat3_at(corners, (uint32_t)ly[r] * row_bytes + x_lo);
       }
