@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench_configs.py -- the BASELINE.json configs that are not the headline benchmark (bench.py).
 
-    python bench_configs.py [--config 2|3|5|all] [--quick]
+    python tests/bench_configs.py [--config 2|3|5|all] [--quick]
+
+(It lives under tests/ because it uses the CPU oracle as the parity checker of configs 2 and 3.)
 
 config 2  300 frames 1920x1080 (LCG seeds 1..300, Lissajous gaze): SAT encode + SAT sample_rect on
           1 GPU; every frame's SAT and reduced frame is then compared with the oracle (digests).
@@ -19,7 +21,7 @@ import subprocess
 import sys
 import time
 
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "tests")]
 
 import numpy as np  # noqa: E402
