@@ -669,6 +669,115 @@ __global__ __launch_bounds__(256) void decode_kernel(
   }
 }
 
+// The same for 4-byte pixels and a width that is a multiple of 4.  A wave owns a 256-pixel
+// strip (4 pixels = 48 table bytes per lane) and walks kDecodeRows rows with the previous
+// row in registers, so a table row is read once (plus one halo row per chunk) instead of
+// twice; the left neighbours arrive by DPP.  Texels outside the frame count as zero, which
+// turns the kernel's four cases (:20-57) into one expression in modular u32 arithmetic.  The
+// fourth byte of every pixel is preserved by a 16-byte read-modify-write owned by one lane.
+constexpr int kDecodeRows = 16;
+constexpr int kDecodeBatch = 4;  // rows whose loads are issued together
+
+typedef uint32_t u32x4_d __attribute__((ext_vector_type(4)));
+
+struct DecodeRow {
+  uint32_t t[12];  // 4 texels x 3 channels
+  uint32_t l[3];   // the texel left of the first one
+};
+
+__device__ __forceinline__ DecodeRow decode_load_row(const uint32_t *__restrict__ sat,
+                                                     size_t row_dw, int y, int x0, int lane,
+                                                     bool has_left_strip) {
+  DecodeRow r;
+  const uint32_t *p = sat + (size_t)y * row_dw + (size_t)3 * x0;
+  const u32x4_d *q = reinterpret_cast<const u32x4_d *>(p);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const u32x4_d v = q[k];
+    r.t[4 * k + 0] = v.x;
+    r.t[4 * k + 1] = v.y;
+    r.t[4 * k + 2] = v.z;
+    r.t[4 * k + 3] = v.w;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) r.l[c] = 0;
+  if (lane == 0 && has_left_strip) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r.l[c] = p[c - 3];
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void decode_strip_kernel(
+    uint8_t *__restrict__ dst, int dst_linesize, const uint32_t *__restrict__ sat, int width,
+    int height, int strips) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int strip = wave % strips;
+  const int y0 = (wave / strips) * kDecodeRows;
+  if (y0 >= height) return;
+  const int x_own = strip * 256 + lane * 4;
+  const bool writes = x_own < width;
+  const int x0 = min(x_own, width - 4);  // idle lanes read in bounds and store nothing
+  const size_t row_dw = (size_t)3 * width;
+  const bool has_left_strip = strip > 0;
+
+  DecodeRow up;
+  if (y0 > 0) {
+    up = decode_load_row(sat, row_dw, y0 - 1, x0, lane, has_left_strip);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) up.t[k] = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) up.l[c] = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const uint32_t from_left = dpp_from_lane_below(up.t[9 + c]);
+    if (lane != 0) up.l[c] = from_left;
+  }
+
+  const int y_end = min(y0 + kDecodeRows, height);
+  for (int yb = y0; yb < y_end; yb += kDecodeBatch) {
+    DecodeRow cur[kDecodeBatch];
+    u32x4_d old[kDecodeBatch];
+#pragma unroll
+    for (int r = 0; r < kDecodeBatch; ++r) {
+      const int y = min(yb + r, height - 1);
+      cur[r] = decode_load_row(sat, row_dw, y, x0, lane, has_left_strip);
+      old[r] = *reinterpret_cast<const u32x4_d *>(dst + (size_t)y * dst_linesize +
+                                                  (size_t)x0 * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < kDecodeBatch; ++r) {
+      if (yb + r >= y_end) break;
+      DecodeRow &c = cur[r];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const uint32_t from_left = dpp_from_lane_below(c.t[9 + ch]);
+        if (lane != 0) c.l[ch] = from_left;
+      }
+      uint32_t px[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t v[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const uint32_t left = k ? c.t[3 * (k - 1) + ch] : c.l[ch];
+          const uint32_t up_left = k ? up.t[3 * (k - 1) + ch] : up.l[ch];
+          v[ch] = min(c.t[3 * k + ch] - up.t[3 * k + ch] + up_left - left, 255u);
+        }
+        const uint32_t keep = k == 0 ? old[r].x : k == 1 ? old[r].y : k == 2 ? old[r].z : old[r].w;
+        px[k] = (keep & 0xff000000u) | v[0] | (v[1] << 8) | (v[2] << 16);
+      }
+      if (writes)
+        *reinterpret_cast<u32x4_d *>(dst + (size_t)(yb + r) * dst_linesize + (size_t)x0 * 4) =
+            u32x4_d{px[0], px[1], px[2], px[3]};
+      up = c;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // interpolate_rect_kernel (src/sat_decoder_interpolate_kernel.cl:1-152).
 // tx / ty hold, per pixel offset from the gaze centre, the inverse map u, the
@@ -1199,6 +1308,20 @@ int f360_satdec_decode(f360_sat_decoder *dec, uint8_t *target_dev,
   F360_REQUIRE(target_dev && sat_dev, "f360_satdec_decode: null buffer");
   F360_REQUIRE(width >= 1 && height >= 1 && target_linesize / width >= 3,
                "f360_satdec_decode: bad geometry");
+  const bool strip_path =
+      width % 4 == 0 && target_linesize % 16 == 0 && target_linesize / width == 4 &&
+      (reinterpret_cast<uintptr_t>(target_dev) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(sat_dev) & 15) == 0;
+  if (strip_path) {
+    const int strips = (width + 255) / 256;
+    const int chunks = (height + kDecodeRows - 1) / kDecodeRows;
+    const int waves = strips * chunks;
+    hipLaunchKernelGGL(decode_strip_kernel, dim3((waves + 3) / 4), dim3(256), 0,
+                       dec->ctx->stream, target_dev, target_linesize, sat_dev, width, height,
+                       strips);
+    F360_HIP_TRY(hipGetLastError());
+    return F360_OK;
+  }
   const dim3 grid((width + 63) / 64, (height + 3) / 4);
   hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, dec->ctx->stream,
                      target_dev, target_linesize, target_linesize / width, sat_dev,

@@ -214,8 +214,9 @@ def test_encode_sample_pipeline_full_size(f360, gpu_ctx, oracle, golden_digests,
 
 
 # --------------------------------------------------------------- decode / interpolate (rect)
-def test_decode_matches_oracle_and_inverts(f360, gpu_ctx, oracle):
-    w, h = 320, 96
+@pytest.mark.parametrize("w,h", [(320, 96), (260, 37), (1024, 50), (322, 19), (8, 3)])
+def test_decode_matches_oracle_and_inverts(f360, gpu_ctx, oracle, w, h):
+    # widths that are multiples of 4 take the strip walker, the others the per-pixel kernel
     frame = oracle.lcg_frame(w, h, 4)
     sat_h = oracle.sat_encode(frame, w, h, 4 * w)
     dec = f360.SATDecoder(gpu_ctx)
