@@ -86,6 +86,10 @@ _SIGNATURES = {
     "f360_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "f360_sat_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "f360_sat_encode_prepare": (c_int, [c_void_p, c_int, c_int]),
+    "f360_yuv420p_to_rgb0": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_int]),
+    "f360_sat_encode_yuv420p": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_int]),
     "f360_satdec_create": (c_int, [c_void_p, POINTER(c_void_p)]),
     "f360_satdec_destroy": (c_int, [c_void_p]),
     "f360_satdec_initialize_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
@@ -96,6 +100,9 @@ _SIGNATURES = {
                                               c_int, c_void_p, c_int, c_int, POINTER(c_float)]),
     "f360_satdec_foveate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                          c_int, c_int, c_float, c_float]),
+    "f360_satdec_foveate_rect_yuv420p": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
+                                                 c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                 c_int, c_int, c_int, c_float, c_float]),
     "f360_satdec_interpolate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_void_p, c_int, c_int, c_int, c_float,
                                              c_float]),
@@ -128,6 +135,7 @@ _SIGNATURES = {
     "f360_tables_is_grid_axis": (c_int, [c_void_p, c_int, c_int]),
     "f360_tables_logpolar_axes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "f360_tables_interp_axis": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "f360_tables_yuv2rgb": (c_int, [c_void_p]),
 }
 
 
@@ -196,6 +204,12 @@ class Context:
         v = c_int(0)
         _check(lib().f360_ctx_get_option(self._h, key.encode(), byref(v)))
         return v.value
+
+    def yuv420p_to_rgb0(self, dst, dst_linesize: int, y, u, v, y_linesize: int,
+                        u_linesize: int, v_linesize: int, width: int, height: int) -> None:
+        """The sws_scale of VideoDecoder::GetFrame (video_decoder.cc:222-224) on the device."""
+        _check(lib().f360_yuv420p_to_rgb0(self._h, _p(dst), dst_linesize, _p(y), _p(u), _p(v),
+                                          y_linesize, u_linesize, v_linesize, width, height))
 
     def profile_arm(self, calls: int) -> None:
         """Sample the next `calls` transform calls with HIP events around each kernel."""
@@ -313,6 +327,19 @@ class SATEncoder:
                                      _p(cl_source_buffer), source_width, source_height,
                                      source_linesize))
 
+    def EncodeFrameYUV420PGPU(self, cl_target_buffer, cl_y, cl_u, cl_v, y_linesize: int,
+                              u_linesize: int, v_linesize: int, source_width: int,
+                              source_height: int) -> None:
+        """Table of the RGB0 frame sws_scale would make of the planes (video_decoder.cc:222),
+        computed from the planes directly.  Not in the reference."""
+        if self.cl_manager is None:
+            raise F360Error(F360_ERR_NOT_INITIALIZED,
+                            "[SATEncoder::EncodeFrameYUV420PGPU] Not initialized with OpenCL")
+        _check(lib().f360_sat_encode_yuv420p(self.cl_manager.handle, _p(cl_target_buffer),
+                                             _p(cl_y), _p(cl_u), _p(cl_v), y_linesize,
+                                             u_linesize, v_linesize, source_width,
+                                             source_height))
+
 
 class SATDecoder:
     """sat_decoder.h:44-82 (device methods)."""
@@ -375,6 +402,16 @@ class SATDecoder:
                                               target_height, target_linesize,
                                               _p(cl_source_frame), source_width, source_height,
                                               source_linesize, center_x, center_y))
+
+    def FoveateFrameRectYUV420PGPU(self, cl_target_buffer, target_width, target_height,
+                                   target_linesize, cl_y, cl_u, cl_v, y_linesize, u_linesize,
+                                   v_linesize, source_width, source_height, center_x,
+                                   center_y) -> None:
+        """FoveateFrameRectGPU from planar YUV 4:2:0.  Not in the reference."""
+        _check(lib().f360_satdec_foveate_rect_yuv420p(
+            self._h, _p(cl_target_buffer), target_width, target_height, target_linesize,
+            _p(cl_y), _p(cl_u), _p(cl_v), y_linesize, u_linesize, v_linesize, source_width,
+            source_height, center_x, center_y))
 
     def InterpolateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
                                 target_linesize, cl_source_buffer, source_width,
@@ -518,6 +555,16 @@ def tables_logpolar_axes(out_w: int, out_h: int):
                                            c.ctypes.data_as(c_void_p),
                                            s.ctypes.data_as(c_void_p), out_w, out_h))
     return r, c, s
+
+
+def tables_yuv2rgb() -> dict:
+    """Constants of libswscale's yuv420p -> RGB converters (host side, no GPU)."""
+    import numpy as np
+    t = np.empty(16, dtype=np.int32)
+    _check(lib().f360_tables_yuv2rgb(t.ctypes.data_as(c_void_p)))
+    names = ("cy", "c0", "crv", "cbu", "cgu", "cgv", "r0", "gu0", "gv0", "b0", "yc", "vrc",
+             "ubc", "vgc", "ugc", "yoff")
+    return {n: int(v) for n, v in zip(names, t)}
 
 
 def tables_interp_axis(value_range: int, n_full: int, n_reduced: int):

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "f360.h"
+#include "yuv_device.h"
 
 namespace f360 {
 
@@ -76,6 +77,7 @@ enum KernelId {
   kGnomonic,
   kFovMaps,
   kFovSample,
+  kYuvToRgb,
   kKernelCount
 };
 struct ProfSpan {
@@ -99,6 +101,7 @@ struct f360_ctx {
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
+  int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;
   std::vector<f360::ProfSpan> prof_pending;
@@ -155,8 +158,9 @@ struct SatEmit {
   uint32_t *corners;
   int corner_stride;
 };
+// `yuv` non-null: the pixels come from three planes (src_dev / linesize unused)
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
-                    int height, int linesize, const SatEmit *emit);
+                    int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv);
 }  // namespace f360
 
 struct f360_event {

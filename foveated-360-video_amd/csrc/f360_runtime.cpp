@@ -247,6 +247,7 @@ static const OptionSlot kOptions[] = {
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
+    {"yuv.model", &f360_ctx::opt_yuv_model},
 };
 
 int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
@@ -259,6 +260,9 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
       if (s.field == &f360_ctx::opt_sb_bands)
         F360_REQUIRE(value >= 0 && value <= 64, "sat.sb_bands out of range: %d",
                      value);
+      if (s.field == &f360_ctx::opt_yuv_model)
+        F360_REQUIRE(value == 0 || value == 1,
+                     "yuv.model must be 0 (libswscale C tables) or 1 (libswscale x86): %d", value);
       if (s.field == &f360_ctx::opt_walk_rows)
         F360_REQUIRE(value >= 1 && value <= 4096, "sample.rows out of range: %d", value);
       ctx->*(s.field) = value;
@@ -284,7 +288,7 @@ static const char *const kKernelNames[f360::kKernelCount] = {
     "sample_rect_kernel",       "interpolate_rect_kernel", "decode_kernel",
     "is_sample_rect_kernel",    "is_sample_logpolar_kernel",
     "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel",
-    "foveate_maps_kernel",      "sample_compact_kernel"};
+    "foveate_maps_kernel",      "sample_compact_kernel",  "yuv420p_to_rgb0_kernel"};
 
 int f360_kernel_count(void) { return f360::kKernelCount; }
 

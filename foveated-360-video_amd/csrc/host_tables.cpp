@@ -35,6 +35,46 @@ inline int radial_f64(unsigned a, int n, float lambda) {
 
 }  // namespace
 
+void build_yuv2rgb_consts(YuvConsts &k) {
+  // ff_yuv2rgb_coeffs[SWS_CS_DEFAULT] (yuv2rgb.c:49-61): {crv, cbu, cgu, cgv} of ITU-R 601
+  int64_t crv = 104597, cbu = 132201, cgu = -25675, cgv = -53279;
+  // limited range: luma gain 255/219, black at 16 (yuv2rgb.c:813-815); contrast and
+  // saturation are 1.0 and brightness 0, so :823-828 change nothing
+  const int64_t cy = ((int64_t)(1 << 16) * 255) / 219;
+  const int64_t oy = (int64_t)16 << 16;
+  // 16-bit lanes of the MMX converter (roundToInt16, yuv2rgb.c:762-772,830-837)
+  auto lane16 = [](int64_t f) {
+    const int r = (int)((f + (1 << 15)) >> 16);
+    return r < -0x7FFF ? -0x8000 : r > 0x7FFF ? 0x7FFF : r;
+  };
+  k.yc = lane16(cy * (1 << 13));
+  k.vrc = lane16(crv * (1 << 13));
+  k.ubc = lane16(cbu * (1 << 13));
+  k.vgc = lane16(cgv * (1 << 13));
+  k.ugc = lane16(cgu * (1 << 13));
+  k.yoff = lane16(oy * (1 << 3));
+  // C converter: chroma increments in table entries (yuv2rgb.c:846-850) ...
+  crv = ((crv * (1 << 16)) + 0x8000) / cy;
+  cbu = ((cbu * (1 << 16)) + 0x8000) / cy;
+  cgu = ((cgu * (1 << 16)) + 0x8000) / cy;
+  cgv = ((cgv * (1 << 16)) + 0x8000) / cy;
+  k.crv = (int)crv;
+  k.cbu = (int)cbu;
+  k.cgu = (int)cgu;
+  k.cgv = (int)cgv;
+  // ... the pointer bias of fill_table / fill_gv_table (:743,:754; >> floors) ...
+  k.r0 = -(int)(crv >> 9);
+  k.b0 = -(int)(cbu >> 9);
+  k.gu0 = -(int)(cgu >> 9);
+  k.gv0 = -(int)(cgv >> 9);
+  // ... and the table itself, entry i = clip8((yb + i * cy + 0x8000) >> 16) with
+  // yb = -(384 << 16) - 512 * cy - oy (:978), read at i = yoffs + offsets + Y,
+  // yoffs = 326 + 512 (:802)
+  const int64_t yb = -((int64_t)384 << 16) - 512 * cy - oy;
+  k.cy = (int)cy;
+  k.c0 = (int)(yb + (326 + 512) * cy + 0x8000);
+}
+
 void build_satdec_grid_axis(std::vector<int16_t> &g, int n_out, int n_src) {
   g.resize((size_t)n_out + 1);
   const float lambda = lambda_of(n_src);
@@ -140,6 +180,16 @@ int f360_tables_logpolar_axes(float *radius, float *cs, float *sn, int out_w, in
   std::memcpy(radius, r.data(), r.size() * sizeof(float));
   std::memcpy(cs, c.data(), c.size() * sizeof(float));
   std::memcpy(sn, s.data(), s.size() * sizeof(float));
+  return F360_OK;
+}
+
+int f360_tables_yuv2rgb(int32_t *out16) {
+  F360_REQUIRE(out16, "f360_tables_yuv2rgb: bad argument");
+  f360::YuvConsts k;
+  f360::build_yuv2rgb_consts(k);
+  const int32_t v[16] = {k.cy,  k.c0, k.crv, k.cbu, k.cgu, k.cgv, k.r0,  k.gu0,
+                         k.gv0, k.b0, k.yc,  k.vrc, k.ubc, k.vgc, k.ugc, k.yoff};
+  std::memcpy(out16, v, sizeof(v));
   return F360_OK;
 }
 

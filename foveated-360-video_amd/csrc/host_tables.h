@@ -10,7 +10,15 @@
 #include <cstdint>
 #include <vector>
 
+#include "yuv_device.h"
+
 namespace f360 {
+
+// Constants of libswscale's yuv420p -> RGB converters for the context the reference creates
+// (src/video_decoder.cc:167-170): ITU-R 601 matrix, limited-range source, brightness 0,
+// contrast = saturation = 1 << 16.  Follows ff_yuv2rgb_c_init_tables
+// (include/FFmpeg42/libswscale/yuv2rgb.c:774-855, 32-bit case :968-993).
+void build_yuv2rgb_consts(YuvConsts &k);
 
 // SATDecoder create_grid_kernel (src/sat_decoder_sample_rect_kernel.cl:243-295),
 // one axis: n_out+1 midpoint offsets.

@@ -1224,12 +1224,16 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
   return F360_OK;
 }
 
-int f360_satdec_foveate_rect(f360_sat_decoder *dec, uint8_t *target_dev, int target_width,
-                             int target_height, int target_linesize,
-                             const uint8_t *source_dev, int source_width, int source_height,
-                             int source_linesize, float center_x, float center_y) {
+}  // extern "C"
+
+namespace {
+// shared by the RGB0 and the planar entry points; `yuv` non-null: pixels come from planes
+int foveate_rect_impl(f360_sat_decoder *dec, uint8_t *target_dev, int target_width,
+                      int target_height, int target_linesize, const uint8_t *source_dev,
+                      int source_width, int source_height, int source_linesize,
+                      float center_x, float center_y, const f360::YuvPlanes *yuv) {
   F360_REQUIRE(dec, "f360_satdec_foveate_rect: null decoder");
-  F360_REQUIRE(target_dev && source_dev, "f360_satdec_foveate_rect: null buffer");
+  F360_REQUIRE(target_dev && (source_dev || yuv), "f360_satdec_foveate_rect: null buffer");
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width,
                "f360_satdec_foveate_rect: bad geometry");
@@ -1285,7 +1289,7 @@ int f360_satdec_foveate_rect(f360_sat_decoder *dec, uint8_t *target_dev, int tar
   if (prof) ctx->prof_armed += 1;  // the encode below belongs to the same sampled call
   f360::SatEmit emit{m.xmap, m.ymap, dec->fov_corners.as<uint32_t>(), cap_x};
   int st = f360::sat_encode_impl(ctx, nullptr, source_dev, source_width, source_height,
-                                 source_linesize, &emit);
+                                 source_linesize, &emit, yuv);
   if (st != F360_OK) return st;
   {
     f360::KernelSpan span(ctx, f360::kFovSample, prof);
@@ -1299,6 +1303,30 @@ int f360_satdec_foveate_rect(f360_sat_decoder *dec, uint8_t *target_dev, int tar
   }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int f360_satdec_foveate_rect(f360_sat_decoder *dec, uint8_t *target_dev, int target_width,
+                             int target_height, int target_linesize,
+                             const uint8_t *source_dev, int source_width, int source_height,
+                             int source_linesize, float center_x, float center_y) {
+  return foveate_rect_impl(dec, target_dev, target_width, target_height, target_linesize,
+                           source_dev, source_width, source_height, source_linesize, center_x,
+                           center_y, nullptr);
+}
+
+int f360_satdec_foveate_rect_yuv420p(f360_sat_decoder *dec, uint8_t *target_dev,
+                                     int target_width, int target_height, int target_linesize,
+                                     const uint8_t *y_dev, const uint8_t *u_dev,
+                                     const uint8_t *v_dev, int y_linesize, int u_linesize,
+                                     int v_linesize, int source_width, int source_height,
+                                     float center_x, float center_y) {
+  const f360::YuvPlanes planes{y_dev, u_dev, v_dev, y_linesize, u_linesize, v_linesize};
+  return foveate_rect_impl(dec, target_dev, target_width, target_height, target_linesize,
+                           nullptr, source_width, source_height, 0, center_x, center_y,
+                           &planes);
 }
 
 int f360_satdec_decode(f360_sat_decoder *dec, uint8_t *target_dev,

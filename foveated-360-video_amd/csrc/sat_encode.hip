@@ -23,8 +23,14 @@
 //   Total HBM traffic ~20.6 B/px against 16 B/px compulsory (the reference's
 //   three passes move 64 B/px).
 #include "f360_internal.h"
+#include "host_tables.h"
 
 namespace {
+
+// Where K1 and K3 take their pixels from (template parameter SRC).  The planar sources
+// convert in registers with libswscale's arithmetic (yuv_device.h), so the table equals the
+// one of the RGB0 frame sws_scale would have produced, without that frame ever existing.
+enum { kSrcBytes = 0, kSrcRgb0 = 1, kSrcYuvSwsC = 2, kSrcYuvSwsX86 = 3 };
 
 constexpr int kLanePx = 4;                 // pixels per lane
 constexpr int kStripPx = 64 * kLanePx;     // pixels per wave-row
@@ -84,13 +90,66 @@ struct EncodeArgs {
   const int *xmap, *ymap;  // source column / row -> compact index, -1 when unused
   uint32_t *corners;       // [compact row][corner_stride][3]
   int corner_stride;
+  // SRC >= kSrcYuvSwsC: the three planes and the conversion constants
+  f360::YuvPlanes yuv;
+  f360::YuvConsts k;
 };
 
+// kRowUnroll rows of a lane's four pixels as loaded; planar sources convert at use, so that
+// the loads of a whole batch stay in flight.
+template <bool YUV>
+struct RowBatchT {
+  uint4 raw[kRowUnroll];  // packed R | G<<8 | B<<16 dwords
+};
+template <>
+struct RowBatchT<true> {
+  uint32_t y4[kRowUnroll];      // four luma bytes per row
+  uint32_t uv[kRowUnroll / 2];  // per row pair: U0 | U1<<8 | V0<<16 | V1<<24
+};
+template <int SRC>
+using RowBatch = RowBatchT<(SRC >= kSrcYuvSwsC)>;
+
+template <int SRC>
+__device__ __forceinline__ void batch_pixels(const EncodeArgs &a, const RowBatch<SRC> &b,
+                                             int r, uint32_t (&v)[4]) {
+  if constexpr (SRC >= kSrcYuvSwsC) {
+    f360::yuv_pixels4<SRC - kSrcYuvSwsC>(a.k, b.y4[r], b.uv[r >> 1], v);
+  } else {
+    v[0] = b.raw[r].x;
+    v[1] = b.raw[r].y;
+    v[2] = b.raw[r].z;
+    v[3] = b.raw[r].w;
+  }
+}
+
+// rows [y, y + kRowUnroll) of a planar source, y a multiple of kRowUnroll; addresses clamped
+// into the frame (what lies outside is masked or never stored by the callers)
+template <int SRC>
+__device__ __forceinline__ void load_yuv_batch(const EncodeArgs &a, RowBatch<SRC> &b, int y,
+                                               int x0) {
+  if constexpr (SRC >= kSrcYuvSwsC) {
+    const int xc = min(x0, a.width - kLanePx);
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r)
+      b.y4[r] = *reinterpret_cast<const uint32_t *>(
+          a.yuv.y + (size_t)min(y + r, a.height - 1) * a.yuv.y_linesize + xc);
+#pragma unroll
+    for (int r = 0; r < kRowUnroll / 2; ++r) {
+      const size_t crow = (size_t)min((y >> 1) + r, (a.height >> 1) - 1);
+      const uint32_t u =
+          *reinterpret_cast<const uint16_t *>(a.yuv.u + crow * a.yuv.u_linesize + (xc >> 1));
+      const uint32_t v =
+          *reinterpret_cast<const uint16_t *>(a.yuv.v + crow * a.yuv.v_linesize + (xc >> 1));
+      b.uv[r] = u | (v << 16);
+    }
+  }
+}
+
 // Four pixels of one row as packed R | G<<8 | B<<16 dwords (0 beyond the row).
-template <bool VEC>
+template <int SRC>
 __device__ __forceinline__ uint4 load_px4(const uint8_t *src, int width, int y,
                                           int x0, int linesize, int bpp) {
-  if (VEC) {
+  if (SRC == kSrcRgb0) {
     if (x0 < width)
       return *reinterpret_cast<const uint4 *>(src + (size_t)y * linesize +
                                               (size_t)x0 * 4);
@@ -150,31 +209,33 @@ struct ReduceState {
   uint32_t tile[3];        // lane 63: strip sums of the rows of the current band
 };
 
-template <bool VEC>
-__device__ __forceinline__ void reduce_load_batch(const EncodeArgs &a,
-                                                  uint4 (&raw)[kRowUnroll], int y,
-                                                  int x0) {
-  if (VEC) {
+template <int SRC>
+__device__ __forceinline__ void reduce_load_batch(const EncodeArgs &a, RowBatch<SRC> &b,
+                                                  int y, int x0) {
+  if constexpr (SRC >= kSrcYuvSwsC) {
+    load_yuv_batch<SRC>(a, b, y, x0);
+  } else if constexpr (SRC == kSrcRgb0) {
     // branch-free: clamp into the frame, validity is applied by the caller's masks
     const int xc = min(x0, a.width - kLanePx);
     const uint8_t *p = a.src + (size_t)xc * 4;
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r)
-      raw[r] = *reinterpret_cast<const uint4 *>(p + (size_t)min(y + r, a.height - 1) *
-                                                        a.linesize);
+      b.raw[r] = *reinterpret_cast<const uint4 *>(p + (size_t)min(y + r, a.height - 1) *
+                                                          a.linesize);
   } else {
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r)
-      raw[r] = (y + r < a.height)
-                   ? load_px4<false>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
-                   : make_uint4(0, 0, 0, 0);
+      b.raw[r] = (y + r < a.height)
+                     ? load_px4<kSrcBytes>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
+                     : make_uint4(0, 0, 0, 0);
   }
 }
 
 // sums rows [y, y + kRowUnroll) that lie below y_stop
+template <int SRC>
 __device__ __forceinline__ void reduce_rows(const EncodeArgs &a, ReduceState &st,
-                                            const uint4 (&raw)[kRowUnroll], int y,
-                                            int y_stop, int strip, int lane) {
+                                            const RowBatch<SRC> &raw, int y, int y_stop,
+                                            int strip, int lane) {
 #pragma unroll
   for (int r = 0; r < kRowUnroll; r += 2) {
     uint32_t rb[2], g[2];
@@ -182,7 +243,8 @@ __device__ __forceinline__ void reduce_rows(const EncodeArgs &a, ReduceState &st
     for (int h = 0; h < 2; ++h) {
       const uint32_t live = (y + r + h < y_stop) ? 0xffffffffu : 0u;  // scalar
       const uint32_t mrb = 0x00ff00ffu & live, mg = 0x0000ff00u & live;
-      const uint32_t v[4] = {raw[r + h].x, raw[r + h].y, raw[r + h].z, raw[r + h].w};
+      uint32_t v[4];
+      batch_pixels<SRC>(a, raw, r + h, v);
       rb[h] = 0;
       g[h] = 0;
 #pragma unroll
@@ -231,7 +293,7 @@ __device__ __forceinline__ void reduce_flush_band(ReduceState &st) {
   }
 }
 
-template <bool VEC>
+template <int SRC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
     const EncodeArgs a) {
   const int lane = threadIdx.x & 63;
@@ -258,16 +320,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
 
   // band_rows is 16, 32 or 64: an even number of batches per band, so the two
   // row buffers alternate with static indices
-  uint4 buf_a[kRowUnroll], buf_b[kRowUnroll];
-  reduce_load_batch<VEC>(a, buf_a, band0 * a.band_rows, x0);
+  RowBatch<SRC> buf_a, buf_b;
+  reduce_load_batch<SRC>(a, buf_a, band0 * a.band_rows, x0);
   for (int band = band0; band < band_end; ++band) {
     store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, st.col);
     const int y_band_end = (band + 1) * a.band_rows;
     for (int y = band * a.band_rows; y < y_band_end; y += 2 * kRowUnroll) {
-      reduce_load_batch<VEC>(a, buf_b, y + kRowUnroll, x0);
-      reduce_rows(a, st, buf_a, y, y_stop, strip, lane);
-      reduce_load_batch<VEC>(a, buf_a, y + 2 * kRowUnroll, x0);
-      reduce_rows(a, st, buf_b, y + kRowUnroll, y_stop, strip, lane);
+      reduce_load_batch<SRC>(a, buf_b, y + kRowUnroll, x0);
+      reduce_rows<SRC>(a, st, buf_a, y, y_stop, strip, lane);
+      reduce_load_batch<SRC>(a, buf_a, y + 2 * kRowUnroll, x0);
+      reduce_rows<SRC>(a, st, buf_b, y + kRowUnroll, y_stop, strip, lane);
     }
     reduce_flush_band(st);
     if (lane == 63) {
@@ -327,9 +389,10 @@ __global__ __launch_bounds__(256) void sat_carry_kernel(const ScanSeg a,
 // STORE 0: three 16-byte stores per lane at a 48-byte lane stride.
 // STORE 1: re-stage the row through wave-private LDS so that each store
 //          instruction writes 1 KiB contiguous.
-template <bool VEC, int STORE>
+template <int SRC, int STORE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
     const EncodeArgs a) {
+  constexpr bool VEC = SRC != kSrcBytes;  // 16-byte accesses allowed (width % 4 == 0, aligned)
   __shared__ __attribute__((aligned(16))) uint32_t
       stage[STORE >= 1 ? kWavesPerBlock * 3 * kStripPx : 4];
   const int lane = threadIdx.x & 63;
@@ -388,17 +451,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   const int y_end = min((band + 1) * a.band_rows, a.height);
   const uint32_t *rc = a.rowcarry + (size_t)strip * a.height * 3;
   for (int y = band * a.band_rows; y < y_end; y += kRowUnroll) {
-    uint4 raw[kRowUnroll];
+    RowBatch<SRC> raw;
+    if constexpr (SRC >= kSrcYuvSwsC) {
+      load_yuv_batch<SRC>(a, raw, y, x0);
+    } else {
 #pragma unroll
-    for (int r = 0; r < kRowUnroll; ++r)
-      raw[r] = (y + r < y_end)
-                   ? load_px4<VEC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
-                   : make_uint4(0, 0, 0, 0);
+      for (int r = 0; r < kRowUnroll; ++r)
+        raw.raw[r] = (y + r < y_end)
+                         ? load_px4<SRC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
+                         : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r) {
       if (y + r >= y_end) break;
       uint32_t c[12];
-      unpack_px4(raw[r], c);
+      {
+        uint32_t v[4];
+        batch_pixels<SRC>(a, raw, r, v);
+        unpack_px4(make_uint4(v[0], v[1], v[2], v[3]), c);
+      }
       // inclusive prefix over the lane's 4 pixels
 #pragma unroll
       for (int k = 1; k < 4; ++k) {
@@ -552,14 +623,29 @@ extern "C" int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height) {
 namespace f360 {
 
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
-                    int height, int linesize, const SatEmit *emit) {
+                    int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv) {
   F360_REQUIRE(ctx, "f360_sat_encode: null context");
-  F360_REQUIRE((sat_dev || emit) && src_dev, "f360_sat_encode: null buffer");
+  F360_REQUIRE((sat_dev || emit) && (src_dev || yuv), "f360_sat_encode: null buffer");
   F360_REQUIRE(width >= 1 && height >= 1, "f360_sat_encode: bad size %dx%d", width,
                height);
-  const int bpp = linesize / width;  // src/sat_encoder_encode_kernels.cl:9
+  const int bpp = yuv ? 4 : linesize / width;  // src/sat_encoder_encode_kernels.cl:9
   F360_REQUIRE(bpp >= 3, "f360_sat_encode: linesize %d gives %d bytes per pixel (need >= 3)",
                linesize, bpp);
+  if (yuv) {
+    F360_REQUIRE(yuv->y && yuv->u && yuv->v, "f360_sat_encode_yuv420p: null plane");
+    // the planar path loads 4 luma bytes and 2 + 2 chroma bytes per lane and row
+    F360_REQUIRE(width % 4 == 0 && height % 2 == 0,
+                 "f360_sat_encode_yuv420p: size %dx%d (need width %% 4 == 0, even height)",
+                 width, height);
+    F360_REQUIRE(yuv->y_linesize >= width && yuv->u_linesize >= width / 2 &&
+                     yuv->v_linesize >= width / 2 && yuv->y_linesize % 4 == 0 &&
+                     yuv->u_linesize % 2 == 0 && yuv->v_linesize % 2 == 0,
+                 "f360_sat_encode_yuv420p: linesizes %d/%d/%d (need >= row, y %% 4, u,v %% 2)",
+                 yuv->y_linesize, yuv->u_linesize, yuv->v_linesize);
+    F360_REQUIRE(((uintptr_t)yuv->y % 4) == 0 && ((uintptr_t)yuv->u % 2) == 0 &&
+                     ((uintptr_t)yuv->v % 2) == 0 && (emit || ((uintptr_t)sat_dev % 16) == 0),
+                 "f360_sat_encode_yuv420p: misaligned plane or table");
+  }
   F360_REQUIRE((size_t)width * height * 3 < ((size_t)1 << 31),
                "f360_sat_encode: frame too large for 32-bit element indices");
   int st = ensure_plan(ctx, width, height);
@@ -592,20 +678,33 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   a.ymap = emit ? emit->ymap : nullptr;
   a.corners = emit ? emit->corners : nullptr;
   a.corner_stride = emit ? emit->corner_stride : 0;
+  a.yuv = yuv ? *yuv : YuvPlanes{nullptr, nullptr, nullptr, 0, 0, 0};
+  if (yuv)
+    build_yuv2rgb_consts(a.k);
+  else
+    a.k = YuvConsts{};
 
   const bool prof = f360::take_profile_slot(ctx);
-  const bool vec = bpp == 4 && (width % 4) == 0 && (linesize % 16) == 0 &&
+  const bool vec = !yuv && bpp == 4 && (width % 4) == 0 && (linesize % 16) == 0 &&
                    ((uintptr_t)src_dev % 16) == 0 &&
                    (emit || ((uintptr_t)sat_dev % 16) == 0);
+  const int yuv_src = !yuv ? 0 : ctx->opt_yuv_model == 1 ? kSrcYuvSwsX86 : kSrcYuvSwsC;
   const dim3 block(64 * kWavesPerBlock);
   const int blocks1 = (p.nstrips * p.nsb + kWavesPerBlock - 1) / kWavesPerBlock;
 
   {
     f360::KernelSpan span(ctx, f360::kSatReduce, prof);
-    if (vec)
-      hipLaunchKernelGGL(sat_reduce_kernel<true>, dim3(blocks1), block, 0, ctx->stream, a);
+    if (yuv_src == kSrcYuvSwsX86)
+      hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsX86>, dim3(blocks1), block, 0,
+                         ctx->stream, a);
+    else if (yuv_src == kSrcYuvSwsC)
+      hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsC>, dim3(blocks1), block, 0, ctx->stream,
+                         a);
+    else if (vec)
+      hipLaunchKernelGGL(sat_reduce_kernel<kSrcRgb0>, dim3(blocks1), block, 0, ctx->stream, a);
     else
-      hipLaunchKernelGGL(sat_reduce_kernel<false>, dim3(blocks1), block, 0, ctx->stream, a);
+      hipLaunchKernelGGL(sat_reduce_kernel<kSrcBytes>, dim3(blocks1), block, 0, ctx->stream,
+                         a);
   }
 
   ScanSeg sa{p.sbtotal, p.sbprefix, p.wp3, p.nsb, (p.wp3 + 255) / 256};
@@ -621,16 +720,24 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   {
     f360::KernelSpan span(ctx, f360::kSatWrite, prof);
     const dim3 grid3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (emit && vec)
-      hipLaunchKernelGGL((sat_write_kernel<true, 2>), grid3, block, 0, ctx->stream, a);
+    if (yuv_src == kSrcYuvSwsX86 && emit)
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsX86, 2>), grid3, block, 0, ctx->stream, a);
+    else if (yuv_src == kSrcYuvSwsX86)
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsX86, 1>), grid3, block, 0, ctx->stream, a);
+    else if (yuv_src == kSrcYuvSwsC && emit)
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsC, 2>), grid3, block, 0, ctx->stream, a);
+    else if (yuv_src == kSrcYuvSwsC)
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsC, 1>), grid3, block, 0, ctx->stream, a);
+    else if (emit && vec)
+      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 2>), grid3, block, 0, ctx->stream, a);
     else if (emit)
-      hipLaunchKernelGGL((sat_write_kernel<false, 2>), grid3, block, 0, ctx->stream, a);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 2>), grid3, block, 0, ctx->stream, a);
     else if (!vec)
-      hipLaunchKernelGGL((sat_write_kernel<false, 0>), grid3, block, 0, ctx->stream, a);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 0>), grid3, block, 0, ctx->stream, a);
     else if (ctx->opt_store_mode == 1)
-      hipLaunchKernelGGL((sat_write_kernel<true, 1>), grid3, block, 0, ctx->stream, a);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 1>), grid3, block, 0, ctx->stream, a);
     else
-      hipLaunchKernelGGL((sat_write_kernel<true, 0>), grid3, block, 0, ctx->stream, a);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 0>), grid3, block, 0, ctx->stream, a);
   }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
@@ -641,5 +748,15 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
 extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev,
                                int width, int height, int linesize) {
   F360_REQUIRE(sat_dev, "f360_sat_encode: null buffer");
-  return f360::sat_encode_impl(ctx, sat_dev, src_dev, width, height, linesize, nullptr);
+  return f360::sat_encode_impl(ctx, sat_dev, src_dev, width, height, linesize, nullptr,
+                               nullptr);
+}
+
+extern "C" int f360_sat_encode_yuv420p(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *y_dev,
+                                       const uint8_t *u_dev, const uint8_t *v_dev,
+                                       int y_linesize, int u_linesize, int v_linesize,
+                                       int width, int height) {
+  F360_REQUIRE(sat_dev, "f360_sat_encode_yuv420p: null buffer");
+  const f360::YuvPlanes planes{y_dev, u_dev, v_dev, y_linesize, u_linesize, v_linesize};
+  return f360::sat_encode_impl(ctx, sat_dev, nullptr, width, height, 0, nullptr, &planes);
 }

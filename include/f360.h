@@ -104,6 +104,29 @@ int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev,
  * that f360_sat_encode itself never allocates (graph-capture safe). */
 int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height);
 
+/* ---- colour-space step in front of the path ----------- */
+/* Replaces the CPU sws_scale of VideoDecoder::GetFrame (src/video_decoder.cc:167-170,
+ * 222-224: sws_getContext(w, h, yuv420p, w, h, AV_PIX_FMT_RGB0, SWS_BILINEAR) + sws_scale):
+ * planar 8-bit YUV 4:2:0 (ITU-R 601, limited range) -> RGB0 with 255 in the fourth byte.
+ * FFmpeg 4.2's libswscale serves that call with its unscaled yuv420p->RGB converter; the
+ * context option "yuv.model" selects which of its two implementations is reproduced bit
+ * for bit: 1 (default) the x86 MMX converter the reference's x86-64 builds run
+ * (include/FFmpeg42/libswscale/x86/yuv2rgb_template.c:84-122,424-443), 0 the table-driven C
+ * converter (libswscale/yuv2rgb.c:70-81,241-262,774-993).  Height must be even (an odd height
+ * takes a different libswscale path); any width. */
+int f360_yuv420p_to_rgb0(f360_ctx *ctx, uint8_t *dst_dev, int dst_linesize,
+                         const uint8_t *y_dev, const uint8_t *u_dev, const uint8_t *v_dev,
+                         int y_linesize, int u_linesize, int v_linesize, int width,
+                         int height);
+/* f360_yuv420p_to_rgb0 + f360_sat_encode in one pass: the table of the RGB0 frame the call
+ * above would write, computed from the planes without materialising that frame (the encoder
+ * reads 1.5 instead of 4 bytes per pixel, twice).  Not in the reference.  Needs
+ * width % 4 == 0, an even height, y_linesize % 4 == 0, even chroma linesizes, planes aligned
+ * to 4 / 2 / 2 bytes and the table to 16. */
+int f360_sat_encode_yuv420p(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *y_dev,
+                            const uint8_t *u_dev, const uint8_t *v_dev, int y_linesize,
+                            int u_linesize, int v_linesize, int width, int height);
+
 /* ---- SATDecoder --------------------------------------------------------- */
 int f360_satdec_create(f360_ctx *ctx, f360_sat_decoder **out);
 int f360_satdec_destroy(f360_sat_decoder *dec);
@@ -147,6 +170,14 @@ int f360_satdec_foveate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
                              int target_linesize, const uint8_t *source_dev,
                              int source_width, int source_height,
                              int source_linesize, float center_x, float center_y);
+/* The same from planar YUV 4:2:0 (f360_sat_encode_yuv420p's requirements). */
+int f360_satdec_foveate_rect_yuv420p(f360_sat_decoder *dec, uint8_t *target_dev,
+                                     int target_width, int target_height,
+                                     int target_linesize, const uint8_t *y_dev,
+                                     const uint8_t *u_dev, const uint8_t *v_dev,
+                                     int y_linesize, int u_linesize, int v_linesize,
+                                     int source_width, int source_height, float center_x,
+                                     float center_y);
 /* SATDecoder::InterpolateFrameRectGPU (src/sat_decoder.h:77-82,
  * src/sat_decoder.cc:887-928; interpolate_rect_kernel
  * src/sat_decoder_interpolate_kernel.cl:1-152).  Like the reference kernel the
@@ -249,6 +280,10 @@ int f360_tables_logpolar_axes(float *radius, float *cs, float *sn, int out_w,
  * (src/sat_decoder_interpolate_kernel.cl:43-89), one axis, indexed by the
  * pixel offset from the gaze centre + range */
 int f360_tables_interp_axis(int32_t *out, int range, int n_full, int n_reduced);
+/* 16 int32 constants of the yuv420p -> RGB converters: cy, c0, crv, cbu, cgu, cgv, r0, gu0,
+ * gv0, b0 (C tables in closed form) and the 16-bit lanes yCoeff, vrCoeff, ubCoeff, vgCoeff,
+ * ugCoeff, yOffset (include/FFmpeg42/libswscale/yuv2rgb.c:774-855) */
+int f360_tables_yuv2rgb(int32_t *out16);
 
 /* ---- tuning / introspection (not part of the reference surface) --------- */
 /* Selects kernel variants for A/B measurements; key/value documented in

@@ -101,6 +101,17 @@ void f360o_is_logpolar_blur(uint8_t *dst, int w, int h, const uint8_t *src);
 void f360o_gnomonic(uint8_t *dst, int dst_w, int dst_h, const uint8_t *src,
                     int src_w, int src_h, float cx, float cy);
 
+/* --- colour-space step in front of the path (f360_oracle_yuv.c) ----------- */
+/* What sws_scale does for src/video_decoder.cc:167-170,222-224 (yuv420p -> RGB0, same size),
+ * restated from the vendored FFmpeg 4.2 libswscale: the table-driven C converter or the x86
+ * MMX converter (they round differently). */
+enum { F360O_YUV_SWS_C = 0, F360O_YUV_SWS_X86 = 1 };
+void f360o_yuv_to_rgb_pixel(int model, int Y, int U, int V, uint8_t *rgb);
+void f360o_yuv420p_to_rgb0(uint8_t *dst, int dst_linesize, const uint8_t *y_plane,
+                           int y_linesize, const uint8_t *u_plane, int u_linesize,
+                           const uint8_t *v_plane, int v_linesize, int width, int height,
+                           int model);
+
 /* --- whole hot path, used by bench.py's cpu_baseline leg ------------------ */
 /* SAT encode + log-rectilinear SAT sample of `frames` frames; frame k is an
  * LCG fill with seed seed0+k, gaze is the Lissajous of SURVEY.md 8d(2).

@@ -43,6 +43,9 @@ def lib() -> ctypes.CDLL:
         L.f360o_satdec_interpolate_rect.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int,
                                                     c_int, c_float, c_float]
         L.f360o_satdec_decode.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int]
+        L.f360o_yuv_to_rgb_pixel.argtypes = [c_int, c_int, c_int, c_int, c_void_p]
+        L.f360o_yuv420p_to_rgb0.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                            c_void_p, c_int, c_int, c_int, c_int]
         L.f360o_is_grid.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
         L.f360o_is_sample_rect.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                            c_int, c_void_p, c_float, c_float]
@@ -178,3 +181,23 @@ def pipeline_encode_sample(frames, src_w, src_h, out_w, out_h, seed0):
     d = lib().f360o_pipeline_encode_sample(frames, src_w, src_h, out_w, out_h, seed0,
                                            ctypes.byref(sec))
     return int(d), sec.value
+
+
+YUV_SWS_C, YUV_SWS_X86 = 0, 1
+
+
+def yuv_to_rgb_pixel(model, Y, U, V):
+    rgb = np.zeros(3, dtype=np.uint8)
+    lib().f360o_yuv_to_rgb_pixel(model, Y, U, V, _ptr(rgb))
+    return tuple(int(c) for c in rgb)
+
+
+def yuv420p_to_rgb0(y, u, v, width, height, model, dst=None, dst_linesize=None) -> np.ndarray:
+    """y: (height, y_linesize), u/v: (height/2, linesize) uint8 arrays."""
+    y, u, v = (np.ascontiguousarray(p, dtype=np.uint8) for p in (y, u, v))
+    if dst is None:
+        dst_linesize = 4 * width
+        dst = np.zeros((height, dst_linesize), dtype=np.uint8)
+    lib().f360o_yuv420p_to_rgb0(_ptr(dst), dst_linesize, _ptr(y), y.shape[1], _ptr(u), u.shape[1],
+                                _ptr(v), v.shape[1], width, height, model)
+    return dst
