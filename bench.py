@@ -97,6 +97,12 @@ def main():
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; 'gloo' only to rehearse the N>1 launch path "
                          "on a box with fewer GPUs than ranks (see --share-device)")
+    ap.add_argument("--source", choices=["rgb0", "yuv420p"], default="rgb0",
+                    help="frame layout handed to the encoder: RGB0 (the reference's; default) or "
+                         "the decoder's planar YUV 4:2:0, converted inside the encode kernels")
+    ap.add_argument("--fused", action="store_true",
+                    help="FoveateFrameRectGPU (encode + sample without writing the table) instead "
+                         "of the two reference calls")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (invalid as a measurement)")
     args = ap.parse_args()
@@ -135,7 +141,15 @@ def main():
     # ---- synthetic, device-resident inputs: B distinct frames per rank -------------------
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    frames = torch.randint(0, 256, (B, h, w * 4), dtype=torch.uint8, device=dev, generator=gen)
+    yuv = args.source == "yuv420p"
+    if yuv:
+        planes_y = torch.randint(0, 256, (B, h, w), dtype=torch.uint8, device=dev, generator=gen)
+        planes_u = torch.randint(0, 256, (B, h // 2, w // 2), dtype=torch.uint8, device=dev,
+                                 generator=gen)
+        planes_v = torch.randint(0, 256, (B, h // 2, w // 2), dtype=torch.uint8, device=dev,
+                                 generator=gen)
+    else:
+        frames = torch.randint(0, 256, (B, h, w * 4), dtype=torch.uint8, device=dev, generator=gen)
     nstreams = max(1, args.streams)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
     ctxs = [f360.Context(local_rank, stream=s.cuda_stream) for s in streams]
@@ -150,7 +164,11 @@ def main():
     sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev) for _ in ctxs]
     reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
     gazes = [lissajous(k) for k in range(B)]
-    frame_ptr = [frames[k].data_ptr() for k in range(B)]
+    if yuv:
+        yuv_ptr = [(planes_y[k].data_ptr(), planes_u[k].data_ptr(), planes_v[k].data_ptr())
+                   for k in range(B)]
+    else:
+        frame_ptr = [frames[k].data_ptr() for k in range(B)]
     red_ptr = [reds[k].data_ptr() for k in range(B)]
     sat_ptr = [s.data_ptr() for s in sats]
     torch.cuda.synchronize(dev)
@@ -165,10 +183,20 @@ def main():
                 for o in range(nstreams):
                     if o != s:
                         streams[s].wait_stream(streams[o])
-                ctxs[s].profile_arm(2)  # this frame's encode and sample calls
-            encs[s].EncodeFrameGPU(sat_ptr[s], frame_ptr[k], w, h, 4 * w)
-            decs[s].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[s], (w, h),
-                                       gazes[k][0], gazes[k][1])
+                ctxs[s].profile_arm(1 if args.fused else 2)  # this frame's transform calls
+            if args.fused and yuv:
+                decs[s].FoveateFrameRectYUV420PGPU(red_ptr[k], rw, rh, 4 * rw, *yuv_ptr[k], w,
+                                                   w // 2, w // 2, w, h, gazes[k][0], gazes[k][1])
+            elif args.fused:
+                decs[s].FoveateFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, frame_ptr[k], w, h, 4 * w,
+                                            gazes[k][0], gazes[k][1])
+            else:
+                if yuv:
+                    encs[s].EncodeFrameYUV420PGPU(sat_ptr[s], *yuv_ptr[k], w, w // 2, w // 2, w, h)
+                else:
+                    encs[s].EncodeFrameGPU(sat_ptr[s], frame_ptr[k], w, h, 4 * w)
+                decs[s].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[s], (w, h),
+                                           gazes[k][0], gazes[k][1])
             if sampled:
                 for o in range(nstreams):
                     if o != s:
@@ -211,6 +239,8 @@ def main():
 
     value = total_px / 1e6 / elapsed
     enc_bytes, smp_bytes = algorithmic_bytes(w, h, rw, rh)
+    if yuv:
+        enc_bytes -= (4 * w * h) - (w * h * 3) // 2  # the frame is 1.5 B/px in planes
 
     if rank == 0:
         # dominant kernel: sat_write_kernel.  Its algorithmic bytes per launch: it is the
@@ -247,9 +277,11 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic" if not args.share_device else "synthetic (REHEARSAL: ranks share GPU 0)",
-            "config": {"workload": f"{w}x{h} RGB0 equirect frames, SAT encode -> log-rectilinear "
-                                   f"SAT sample to {rw}x{rh}, batch {B} frames per GPU per step, "
-                                   f"Lissajous gaze, inputs resident in HBM",
+            "config": {"workload": f"{w}x{h} {'planar YUV 4:2:0' if yuv else 'RGB0'} equirect frames, "
+                                   f"{'fused SAT encode + ' if args.fused else 'SAT encode -> '}"
+                                   f"log-rectilinear SAT sample to {rw}x{rh}, batch {B} frames per "
+                                   f"GPU per step, Lissajous gaze, inputs resident in HBM",
+                       "source": args.source, "fused": bool(args.fused),
                        "frame": [w, h], "reduced": [rw, rh], "batch_per_gpu": B,
                        "streams_per_gpu": nstreams, "parallelism": f"frames sharded x{world}"},
             "roofline": roof,

@@ -29,7 +29,8 @@ from ctypes import (POINTER, byref, c_char_p, c_float, c_int, c_int16, c_size_t,
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "lib", "libf360.so")
+# F360_LIBRARY: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("F360_LIBRARY") or os.path.join(_HERE, "lib", "libf360.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F360_OK = 0

@@ -319,7 +319,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
   const int y_stop = min(band_end * a.band_rows, a.height);
 
   // band_rows is 16, 32 or 64: an even number of batches per band, so the two
-  // row buffers alternate with static indices
+  // row buffers alternate with static indices.  (Four batches in flight measured the same as
+  // two: with at most one of these waves per SIMD the kernel is bound by its own instruction
+  // stream, not by the memory latency.)
   RowBatch<SRC> buf_a, buf_b;
   reduce_load_batch<SRC>(a, buf_a, band0 * a.band_rows, x0);
   for (int band = band0; band < band_end; ++band) {
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   }
 }
 
-int ensure_plan(f360_ctx *ctx, int width, int height) {
+int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false) {
   f360::SatEncodePlan &p = ctx->enc;
   // band height: the largest of 64 / 32 / 16 rows that still yields enough tiles (one wave
   // each in the writer) to fill 256 CUs -- 64 at 7680x3840, 16 at 3840x1920 and below
@@ -569,7 +571,10 @@ int ensure_plan(f360_ctx *ctx, int width, int height) {
   }
   // bands per reducer wave: at least 2, and few enough super-bands (<= 32) that the carry
   // kernel needs a single round of loads
+  // (planar sources convert in the reducer, which makes it instruction-bound: one band per
+  // wave doubles the waves, 45 -> 34 us at 8K)
   int sb_bands = ctx->opt_sb_bands;
+  if (sb_bands < 0) sb_bands = planar ? 1 : 2;
   if (sb_bands == 0) {
     const int nb = (height + band_rows - 1) / band_rows;
     sb_bands = (nb + 31) / 32;
@@ -648,7 +653,7 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   }
   F360_REQUIRE((size_t)width * height * 3 < ((size_t)1 << 31),
                "f360_sat_encode: frame too large for 32-bit element indices");
-  int st = ensure_plan(ctx, width, height);
+  int st = ensure_plan(ctx, width, height, yuv != nullptr);
   if (st != F360_OK) return st;
   const f360::SatEncodePlan &p = ctx->enc;
 
@@ -707,6 +712,7 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                          a);
   }
 
+  if (ctx->opt_ablate & 8) return F360_OK;  // timing experiments: reducer only
   ScanSeg sa{p.sbtotal, p.sbprefix, p.wp3, p.nsb, (p.wp3 + 255) / 256};
   ScanSeg sb{p.rowsum, p.rowcarry, height * 3, p.nstrips, (height * 3 + 255) / 256};
   ScanSeg sc{p.tiletotal, p.tprefix, p.nbands * 3, p.nstrips,
