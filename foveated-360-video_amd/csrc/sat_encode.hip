@@ -36,6 +36,10 @@ constexpr int kLanePx = 4;                 // pixels per lane
 constexpr int kStripPx = 64 * kLanePx;     // pixels per wave-row
 constexpr int kWavesPerBlock = 4;
 constexpr int kRowUnroll = 8;              // rows whose loads are issued together
+#ifndef F360_REDUCE_DEPTH
+#define F360_REDUCE_DEPTH 2
+#endif
+constexpr int kReduceDepth = F360_REDUCE_DEPTH;  // batches a reducer wave keeps in flight
 
 // ---- wave64 DPP helpers ---------------------------------------------------
 // dpp_ctrl: 0x110+n row_shr:n, 0x142 row_bcast:15, 0x143 row_bcast:31.
@@ -75,6 +79,16 @@ __device__ __forceinline__ void lds_read3_b128(uint32_t addr, u32x4 &a, u32x4 &b
       : "=&v"(a), "=&v"(b), "=&v"(c)
       : "v"(addr)
       : "memory");
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_write_b64(uint32_t addr, uint32_t a, uint32_t b) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(u32x2{a, b}) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
 }
 
 struct EncodeArgs {
@@ -122,20 +136,21 @@ __device__ __forceinline__ void batch_pixels(const EncodeArgs &a, const RowBatch
   }
 }
 
-// rows [y, y + kRowUnroll) of a planar source, y a multiple of kRowUnroll; addresses clamped
-// into the frame (what lies outside is masked or never stored by the callers)
+// rows [y, y + kRowUnroll) of a planar source, y a multiple of kRowUnroll; rows past y_last
+// (odd: the last row of the frame or of the caller's run of rows) re-read that row -- what lies
+// past it is masked or never stored by the callers
 template <int SRC>
 __device__ __forceinline__ void load_yuv_batch(const EncodeArgs &a, RowBatch<SRC> &b, int y,
-                                               int x0) {
+                                               int x0, int y_last) {
   if constexpr (SRC >= kSrcYuvSwsC) {
     const int xc = min(x0, a.width - kLanePx);
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r)
       b.y4[r] = *reinterpret_cast<const uint32_t *>(
-          a.yuv.y + (size_t)min(y + r, a.height - 1) * a.yuv.y_linesize + xc);
+          a.yuv.y + (size_t)min(y + r, y_last) * a.yuv.y_linesize + xc);
 #pragma unroll
     for (int r = 0; r < kRowUnroll / 2; ++r) {
-      const size_t crow = (size_t)min((y >> 1) + r, (a.height >> 1) - 1);
+      const size_t crow = (size_t)min((y >> 1) + r, y_last >> 1);
       const uint32_t u =
           *reinterpret_cast<const uint16_t *>(a.yuv.u + crow * a.yuv.u_linesize + (xc >> 1));
       const uint32_t v =
@@ -211,17 +226,17 @@ struct ReduceState {
 
 template <int SRC>
 __device__ __forceinline__ void reduce_load_batch(const EncodeArgs &a, RowBatch<SRC> &b,
-                                                  int y, int x0) {
+                                                  int y, int x0, int y_last) {
   if constexpr (SRC >= kSrcYuvSwsC) {
-    load_yuv_batch<SRC>(a, b, y, x0);
+    load_yuv_batch<SRC>(a, b, y, x0, y_last);
   } else if constexpr (SRC == kSrcRgb0) {
-    // branch-free: clamp into the frame, validity is applied by the caller's masks
+    // branch-free: rows past the wave's last row re-read that row (a cache hit), validity is
+    // applied by the caller's masks
     const int xc = min(x0, a.width - kLanePx);
     const uint8_t *p = a.src + (size_t)xc * 4;
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r)
-      b.raw[r] = *reinterpret_cast<const uint4 *>(p + (size_t)min(y + r, a.height - 1) *
-                                                          a.linesize);
+      b.raw[r] = *reinterpret_cast<const uint4 *>(p + (size_t)min(y + r, y_last) * a.linesize);
   } else {
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r)
@@ -231,11 +246,12 @@ __device__ __forceinline__ void reduce_load_batch(const EncodeArgs &a, RowBatch<
   }
 }
 
-// sums rows [y, y + kRowUnroll) that lie below y_stop
+// sums rows [y, y + kRowUnroll) that lie below y_stop; the strip's row sums go to the wave's
+// LDS slice `rows_lds` (byte address of the band's first row), see reduce_store_rowsums
 template <int SRC>
 __device__ __forceinline__ void reduce_rows(const EncodeArgs &a, ReduceState &st,
                                             const RowBatch<SRC> &raw, int y, int y_stop,
-                                            int strip, int lane) {
+                                            int row_in_band, uint32_t rows_lds, int lane) {
 #pragma unroll
   for (int r = 0; r < kRowUnroll; r += 2) {
     uint32_t rb[2], g[2];
@@ -265,19 +281,31 @@ __device__ __forceinline__ void reduce_rows(const EncodeArgs &a, ReduceState &st
       tg = wave_scan_incl(tg);
     }
     if (lane == 63 && y + r < y_stop && !(a.ablate & 2)) {
-      uint32_t *rs = a.rowsum + ((size_t)strip * a.height + (y + r)) * 3;
-      rs[0] = t0 & 0xffffu;
-      rs[1] = tg & 0xffffu;
-      rs[2] = t0 >> 16;
-      if (y + r + 1 < y_stop) {
-        rs[3] = t1 & 0xffffu;
-        rs[4] = tg >> 16;
-        rs[5] = t1 >> 16;
-      }
+      // rows past y_stop were masked to zero above, so both rows can be written
+      const uint32_t at = rows_lds + (uint32_t)(row_in_band + r) * 12;
+      lds_write_b64(at, t0 & 0xffffu, tg & 0xffffu);
+      lds_write_b64(at + 8, t0 >> 16, t1 & 0xffffu);
+      lds_write_b64(at + 16, tg >> 16, t1 >> 16);
       st.tile[0] += (t0 & 0xffffu) + (t1 & 0xffffu);
       st.tile[1] += (tg & 0xffffu) + (tg >> 16);
       st.tile[2] += (t0 >> 16) + (t1 >> 16);
     }
+  }
+}
+
+// One band's row sums, LDS -> rowsum[strip][y][3], 256 contiguous bytes per store instruction.
+// They are kept out of the row loop on purpose: a global store between the loads and their use
+// makes the compiler wait for (almost) everything in flight, because loads and stores share
+// vmcnt on gfx9-class hardware and complete out of order relative to each other.
+__device__ __forceinline__ void reduce_store_rowsums(const EncodeArgs &a, uint32_t rows_lds,
+                                                     int strip, int band_y0, int y_stop,
+                                                     int lane) {
+  const int n = min(a.band_rows, y_stop - band_y0) * 3;
+  uint32_t *dst = a.rowsum + ((size_t)strip * a.height + band_y0) * 3;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int i = q * 64 + lane;
+    if (i < n) dst[i] = lds_read_b32(rows_lds + (uint32_t)i * 4);
   }
 }
 
@@ -296,7 +324,10 @@ __device__ __forceinline__ void reduce_flush_band(ReduceState &st) {
 template <int SRC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
     const EncodeArgs a) {
+  __shared__ uint32_t rowsum_stage[kWavesPerBlock * 64 * 3];  // one band of row sums per wave
   const int lane = threadIdx.x & 63;
+  const uint32_t rows_lds = (uint32_t)reinterpret_cast<uintptr_t>(rowsum_stage) +
+                            (uint32_t)(threadIdx.x >> 6) * 64 * 3 * 4;
   // 1-D grid over the tiles in row-major order, 4 consecutive tiles per workgroup: every
   // workgroup is full, so the round-robin of workgroups over the 8 XCDs stays balanced (a 2-D
   // grid with 8 workgroup columns pins each strip group to one XCD, the ragged last one too)
@@ -318,29 +349,45 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
   const int band_end = min(band0 + a.sb_bands, a.nbands);
   const int y_stop = min(band_end * a.band_rows, a.height);
 
-  // band_rows is 16, 32 or 64: an even number of batches per band, so the two
-  // row buffers alternate with static indices.  (Four batches in flight measured the same as
-  // two: with at most one of these waves per SIMD the kernel is bound by its own instruction
-  // stream, not by the memory latency.)
-  RowBatch<SRC> buf_a, buf_b;
-  reduce_load_batch<SRC>(a, buf_a, band0 * a.band_rows, x0);
-  for (int band = band0; band < band_end; ++band) {
-    store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, st.col);
-    const int y_band_end = (band + 1) * a.band_rows;
-    for (int y = band * a.band_rows; y < y_band_end; y += 2 * kRowUnroll) {
-      reduce_load_batch<SRC>(a, buf_b, y + kRowUnroll, x0);
-      reduce_rows<SRC>(a, st, buf_a, y, y_stop, strip, lane);
-      reduce_load_batch<SRC>(a, buf_a, y + 2 * kRowUnroll, x0);
-      reduce_rows<SRC>(a, st, buf_b, y + kRowUnroll, y_stop, strip, lane);
+  // The super-band is a run of batches of kRowUnroll rows with kReduceDepth of them in flight.
+  // Loads are unconditional (clamped to the wave's last row): a load inside a branch makes the
+  // compiler wait for ALL outstanding loads at the next use (it cannot count what is in flight
+  // on both paths), which silently turns any depth into one.  Buffers rotate with static
+  // indices; band boundaries fall on batch boundaries (band_rows is 16, 32 or 64).
+  RowBatch<SRC> buf[kReduceDepth];
+  const int y_first = band0 * a.band_rows;
+  const int y_last = y_stop - 1;
+  const int bpb = a.band_rows / kRowUnroll;  // batches per band
+  const int nbatch = (band_end - band0) * bpb;
+#pragma unroll
+  for (int d = 0; d < kReduceDepth - 1; ++d)
+    reduce_load_batch<SRC>(a, buf[d], y_first + d * kRowUnroll, x0, y_last);
+  for (int t0 = 0; t0 < nbatch; t0 += kReduceDepth) {
+#pragma unroll
+    for (int d = 0; d < kReduceDepth; ++d) {
+      const int t = t0 + d;
+      reduce_load_batch<SRC>(a, buf[(d + kReduceDepth - 1) % kReduceDepth],
+                             y_first + (t + kReduceDepth - 1) * kRowUnroll, x0, y_last);
+      if (t < nbatch) {
+        const int band = band0 + t / bpb;
+        const int in_band = t % bpb;
+        if (in_band == 0) store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, st.col);
+        reduce_rows<SRC>(a, st, buf[d], y_first + t * kRowUnroll, y_stop,
+                         in_band * kRowUnroll, rows_lds, lane);
+        if (in_band == bpb - 1) {
+          if (!(a.ablate & 2))
+            reduce_store_rowsums(a, rows_lds, strip, band * a.band_rows, y_stop, lane);
+          reduce_flush_band(st);
+          if (lane == 63) {
+            uint32_t *tt = a.tiletotal + ((size_t)strip * a.nbands + band) * 3;
+            tt[0] = st.tile[0];
+            tt[1] = st.tile[1];
+            tt[2] = st.tile[2];
+          }
+          st.tile[0] = st.tile[1] = st.tile[2] = 0;
+        }
+      }
     }
-    reduce_flush_band(st);
-    if (lane == 63) {
-      uint32_t *tt = a.tiletotal + ((size_t)strip * a.nbands + band) * 3;
-      tt[0] = st.tile[0];
-      tt[1] = st.tile[1];
-      tt[2] = st.tile[2];
-    }
-    st.tile[0] = st.tile[1] = st.tile[2] = 0;
   }
   store12(a.sbtotal + (size_t)sb * a.wp3 + (size_t)x0 * 3, st.col);
 }
@@ -455,7 +502,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   for (int y = band * a.band_rows; y < y_end; y += kRowUnroll) {
     RowBatch<SRC> raw;
     if constexpr (SRC >= kSrcYuvSwsC) {
-      load_yuv_batch<SRC>(a, raw, y, x0);
+      load_yuv_batch<SRC>(a, raw, y, x0, a.height - 1);
     } else {
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r)
