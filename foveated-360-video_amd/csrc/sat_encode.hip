@@ -91,6 +91,17 @@ __device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr) {
   return v;
 }
 
+// A 16-byte global store the compiler does not see as a memory operation.  Loads and stores share
+// one counter (vmcnt) on this hardware and complete out of order relative to each other, so
+// with a store pending the compiler turns every wait for a load into vmcnt(0), i.e. into a wait
+// for the acknowledgement of all earlier stores as well.  Hidden from its bookkeeping, a wait
+// for a load is vmcnt(number of younger loads): still sufficient (loads complete in order; the
+// extra pending stores can only make the wait longer, never shorter) and it no longer drains
+// the stores.  The s_nop covers the store-data hazard (data > 8 bytes overwritten next).
+__device__ __forceinline__ void global_store_b128_uncounted(uint32_t *p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 struct EncodeArgs {
   uint32_t *sat;
   const uint8_t *src;
@@ -499,17 +510,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
 
   const int y_end = min((band + 1) * a.band_rows, a.height);
   const uint32_t *rc = a.rowcarry + (size_t)strip * a.height * 3;
-  for (int y = band * a.band_rows; y < y_end; y += kRowUnroll) {
-    RowBatch<SRC> raw;
-    if constexpr (SRC >= kSrcYuvSwsC) {
-      load_yuv_batch<SRC>(a, raw, y, x0, a.height - 1);
-    } else {
+  // A batch = kRowUnroll rows of pixels plus their row carries (3 dwords per row, fetched by
+  // lanes 0..23 in one load and broadcast with v_readlane: a per-row load of a wave-uniform
+  // address would be one more vector-memory operation to wait for in every row).  No branch
+  // around any load (addresses are clamped to the band's last row): see sat_reduce_kernel.
+  auto load_batch = [&](RowBatch<SRC> &raw, uint32_t &carry, int y) {
+    if constexpr (SRC == kSrcBytes) {
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r)
         raw.raw[r] = (y + r < y_end)
                          ? load_px4<SRC>(a.src, a.width, y + r, x0, a.linesize, a.bpp)
                          : make_uint4(0, 0, 0, 0);
+    } else {
+      reduce_load_batch<SRC>(a, raw, y, x0, y_end - 1);
     }
+    carry = rc[min(y * 3 + min(lane, 3 * kRowUnroll - 1), a.height * 3 - 1)];
+  };
+  auto write_batch = [&](const RowBatch<SRC> &raw, uint32_t carry, int y) {
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r) {
       if (y + r >= y_end) break;
@@ -528,9 +545,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
       }
       const uint32_t inc_rg = wave_scan_incl(c[9] | (c[10] << 16));
       const uint32_t inc_b = wave_scan_incl(c[11]);
-      const uint32_t base_r = (inc_rg & 0xffffu) - c[9] + rc[(size_t)(y + r) * 3 + 0];
-      const uint32_t base_g = (inc_rg >> 16) - c[10] + rc[(size_t)(y + r) * 3 + 1];
-      const uint32_t base_b = inc_b - c[11] + rc[(size_t)(y + r) * 3 + 2];
+      const uint32_t base_r =
+          (inc_rg & 0xffffu) - c[9] + (uint32_t)__builtin_amdgcn_readlane((int)carry, 3 * r);
+      const uint32_t base_g =
+          (inc_rg >> 16) - c[10] + (uint32_t)__builtin_amdgcn_readlane((int)carry, 3 * r + 1);
+      const uint32_t base_b =
+          inc_b - c[11] + (uint32_t)__builtin_amdgcn_readlane((int)carry, 3 * r + 2);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         acc[3 * k + 0] += c[3 * k + 0] + base_r;
@@ -554,7 +574,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
             uint32_t *dst = crow + (size_t)xm_first * 3;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-              *reinterpret_cast<u32x4_a4 *>(dst + q * 256 + lane * 4) = v[q];
+              global_store_b128_uncounted(dst + q * 256 + lane * 4, v[q]);
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -587,7 +607,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
         for (int q = 0; q < 3; ++q) {
           const int off = q * 256 + lane * 4;
           if (base + off < row_dwords)  // width % 4 == 0 -> whole 16 B in range
-            *reinterpret_cast<u32x4 *>(row + base + off) = v[q];
+            global_store_b128_uncounted(row + base + off, v[q]);
         }
       } else {
 #pragma unroll
@@ -599,6 +619,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
           }
       }
     }
+  };
+  // two batches alternate (a band is 2, 4 or 8 batches): the next one is in flight while this
+  // one is scanned and stored
+  RowBatch<SRC> buf_a, buf_b;
+  uint32_t carry_a, carry_b;
+  const int y_begin = band * a.band_rows;
+  load_batch(buf_a, carry_a, y_begin);
+  for (int y = y_begin; y < y_end; y += 2 * kRowUnroll) {
+    load_batch(buf_b, carry_b, y + kRowUnroll);
+    write_batch(buf_a, carry_a, y);
+    load_batch(buf_a, carry_a, y + 2 * kRowUnroll);
+    if (y + kRowUnroll < y_end) write_batch(buf_b, carry_b, y + kRowUnroll);
   }
 }
 
