@@ -102,6 +102,13 @@ __device__ __forceinline__ void global_store_b128_uncounted(uint32_t *p, u32x4 v
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+typedef uint32_t u32x3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void global_store_b96_uncounted(uint32_t *p, uint32_t x, uint32_t y,
+                                                           uint32_t z) {
+  asm volatile("global_store_dwordx3 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(u32x3v{x, y, z})
+               : "memory");
+}
+
 struct EncodeArgs {
   uint32_t *sat;
   const uint8_t *src;
@@ -524,7 +531,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
     } else {
       reduce_load_batch<SRC>(a, raw, y, x0, y_end - 1);
     }
-    carry = rc[min(y * 3 + min(lane, 3 * kRowUnroll - 1), a.height * 3 - 1)];
+    const uint32_t *cp = rc + min(y * 3 + min(lane, 3 * kRowUnroll - 1), a.height * 3 - 1);
+    if (STORE == 2 && lane >= 32)  // emit mode: lanes 32..39 fetch the rows' compact indices
+      cp = reinterpret_cast<const uint32_t *>(a.ymap) +
+           min(y + min(lane - 32, kRowUnroll - 1), a.height - 1);
+    carry = *cp;
   };
   auto write_batch = [&](const RowBatch<SRC> &raw, uint32_t carry, int y) {
 #pragma unroll
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
         acc[3 * k + 2] += c[3 * k + 2] + base_b;
       }
       if (STORE == 2) {
-        const int py = a.ymap[y + r];  // wave-uniform
+        const int py = __builtin_amdgcn_readlane((int)carry, 32 + r);  // a.ymap[y + r]
         if (py >= 0) {
           uint32_t *crow = a.corners + (size_t)py * a.corner_stride * 3;
           if (dense) {
@@ -579,8 +590,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               if (xm[k] >= 0) {  // one 12-byte store per lattice texel
-                u32x3 v = {acc[3 * k + 0], acc[3 * k + 1], acc[3 * k + 2]};
-                *reinterpret_cast<u32x3 *>(crow + (size_t)xm[k] * 3) = v;
+                global_store_b96_uncounted(crow + (size_t)xm[k] * 3, acc[3 * k + 0],
+                                           acc[3 * k + 1], acc[3 * k + 2]);
               }
           }
         }
