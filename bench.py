@@ -245,25 +245,32 @@ def main():
     if rank == 0:
         # dominant kernel: sat_write_kernel.  Its algorithmic bytes per launch: it is the
         # kernel that produces the table, so it is charged the encode's compulsory traffic
-        # (4 B/px frame read + 12 B/px table write; DESIGN.md "Roofline accounting").
+        # (4 B/px frame read -- 1.5 from planes -- + 12 B/px table write; DESIGN.md "Roofline
+        # accounting").  In fused mode it emits the distinct box corners instead of the table:
+        # frame read + 12 B per corner.
         dom = "sat_write_kernel"
         roof = None
+        frame_bytes = (w * h * 3) // 2 if yuv else 4 * w * h
         if dom in kernels:
             avg_s = kernels[dom]["avg_us"] * 1e-6
-            achieved = enc_bytes / avg_s / 1e9
+            dom_bytes = frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes
+            achieved = dom_bytes / avg_s / 1e9
             traffic = None
             tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and not args.fused:
                 try:
                     with open(tpath) as f:
-                        traffic = json.load(f).get(dom, {}).get(f"{w}x{h}")
+                        traffic = json.load(f).get(dom, {}).get(f"{w}x{h}" + (":yuv420p" if yuv else ""))
                 except Exception:
                     traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+            roof = {"bound": "hbm", "kernel": dom + (" (emit mode)" if args.fused else ""),
+                    "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": enc_bytes,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
                     "avg_launch_us": kernels[dom]["avg_us"]}
-        path_bytes = enc_bytes + smp_bytes
+        # whole path: SURVEY 8(d)'s figure for the two calls; fused, the table and its re-read are
+        # not algorithmic work any more: frame in + reduced frame out
+        path_bytes = (frame_bytes + 4 * rw * rh) if args.fused else enc_bytes + smp_bytes
         line = {
             "metric": "Mpixels/s (SAT+log-rectilinear warp), 8K equirect frames",
             "value": round(value, 1),

@@ -42,9 +42,24 @@ def main():
         view = ctx.malloc((w // 2) * (h // 2) * 4)
         enc.EncodeFrameGPU(sat.ptr, frames[0].ptr, w, h, 4 * w)
         dec.SampleFrameRectGPU(red.ptr, rw, rh, 4 * rw, sat.ptr, (w, h), 0.5, 0.5)
+        ys = [ctx.upload(rng.integers(0, 256, (h, w), dtype=np.uint8)) for _ in range(nbuf)]
+        us_ = [ctx.upload(rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)) for _ in range(nbuf)]
+        vs = [ctx.upload(rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)) for _ in range(nbuf)]
+        yuv_args = lambda k: (ys[k % nbuf].ptr, us_[k % nbuf].ptr, vs[k % nbuf].ptr, w, w // 2, w // 2)
         cases = [
             ("sat_encode (3 kernels)", 16 * w * h,
              lambda k: enc.EncodeFrameGPU(sat.ptr, frames[k % nbuf].ptr, w, h, 4 * w)),
+            ("yuv420p_to_rgb0", w * h * 3 // 2 + 4 * w * h,
+             lambda k: ctx.yuv420p_to_rgb0(full.ptr, 4 * w, *yuv_args(k), w, h)),
+            ("sat_encode from yuv420p (3 kernels)", w * h * 3 // 2 + 12 * w * h,
+             lambda k: enc.EncodeFrameYUV420PGPU(sat.ptr, *yuv_args(k), w, h)),
+            ("foveate_rect (fused encode+sample, 5 kernels)",
+             4 * w * h + 4 * rw * rh,
+             lambda k: dec.FoveateFrameRectGPU(red.ptr, rw, rh, 4 * rw, frames[k % nbuf].ptr, w, h, 4 * w,
+                                               0.4 + 0.01 * k, 0.5)),
+            ("foveate_rect from yuv420p", w * h * 3 // 2 + 4 * rw * rh,
+             lambda k: dec.FoveateFrameRectYUV420PGPU(red.ptr, rw, rh, 4 * rw, *yuv_args(k), w, h,
+                                                      0.4 + 0.01 * k, 0.5)),
             ("sample_rect (SAT)", 12 * (rw + 1) * (rh + 1) + 4 * rw * rh,
              lambda k: dec.SampleFrameRectGPU(red.ptr, rw, rh, 4 * rw, sat.ptr, (w, h), 0.4 + 0.01 * k, 0.5)),
             ("interpolate_rect", 4 * rw * rh + 4 * w * h,
