@@ -96,6 +96,27 @@ class SATDecoder {
                 << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 
+  // The same from a decoder's yuv420p planes (f360_sat_encode_yuv420p's requirements).
+  void FoveateFrameRectYUV420PGPU(cl_mem cl_target_buffer, int target_width, int target_height,
+                                  int target_linesize, cl_mem cl_y, cl_mem cl_u, cl_mem cl_v,
+                                  int y_linesize, int u_linesize, int v_linesize,
+                                  int source_width, int source_height, float center_x,
+                                  float center_y) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::FoveateFrameRectYUV420PGPU] Not initialized with OpenCL"
+                << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_foveate_rect_yuv420p(
+        impl, static_cast<uint8_t *>(cl_target_buffer), target_width, target_height,
+        target_linesize, static_cast<const uint8_t *>(cl_y), static_cast<const uint8_t *>(cl_u),
+        static_cast<const uint8_t *>(cl_v), y_linesize, u_linesize, v_linesize, source_width,
+        source_height, center_x, center_y);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::FoveateFrameRectYUV420PGPU] kernel launch failed:" << ret
+                << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
   // src/sat_decoder.cc:887-928
   void InterpolateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
                                int target_linesize, cl_mem cl_source_buffer, int source_width,

@@ -35,4 +35,23 @@ class SATEncoder {
       std::cerr << "[SATEncoder::EncodeFrameGPU] kernel launch failed:" << ret << " "
                 << f360_last_error_string() << std::endl;
   }
+
+  // Not in the reference: the table of the RGB0 frame sws_scale would make of a decoder's
+  // yuv420p planes (src/video_decoder.cc:222-224), computed from the planes directly.
+  void EncodeFrameYUV420PGPU(cl_mem cl_target_buffer, cl_mem cl_y, cl_mem cl_u, cl_mem cl_v,
+                             int y_linesize, int u_linesize, int v_linesize, int source_width,
+                             int source_height) {
+    if (!use_OpenCL) {
+      std::cerr << "[SATEncoder::EncodeFrameYUV420PGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_sat_encode_yuv420p(
+        cl_manager->context.get(), static_cast<uint32_t *>(cl_target_buffer),
+        static_cast<const uint8_t *>(cl_y), static_cast<const uint8_t *>(cl_u),
+        static_cast<const uint8_t *>(cl_v), y_linesize, u_linesize, v_linesize, source_width,
+        source_height);
+    if (ret != F360_OK)
+      std::cerr << "[SATEncoder::EncodeFrameYUV420PGPU] kernel launch failed:" << ret << " "
+                << f360_last_error_string() << std::endl;
+  }
 };
