@@ -506,8 +506,10 @@ struct FovMaps {
 
 constexpr int kFovLdsEntries = 16384;  // axis lengths up to this are ranked in LDS
 
+constexpr int kFovPerThread = 8;  // boxes a thread keeps in registers (axes up to 8192 outputs)
+
 __global__ __launch_bounds__(1024) void foveate_maps_kernel(const FovMaps m) {
-  __shared__ int part[1024];
+  __shared__ int part[16];
   __shared__ int lflag[kFovLdsEntries];
   const bool is_x = blockIdx.x == 0;
   const int size = is_x ? m.src_w : m.src_h, n_out = is_x ? m.out_w : m.out_h;
@@ -517,9 +519,28 @@ __global__ __launch_bounds__(1024) void foveate_maps_kernel(const FovMaps m) {
   int *ih = is_x ? m.ihx : m.ihy, *il = is_x ? m.ilx : m.ily, *dw = is_x ? m.dxw : m.dyw;
   int *flag = size <= kFovLdsEntries ? lflag : map;  // LDS when it fits, else in place
   const int t = threadIdx.x;
+  // this thread's boxes: all grid loads are issued before anything depends on them, and the
+  // boxes stay in registers for the last phase (the kernel is a chain of round trips otherwise)
+  const bool in_regs = n_out <= kFovPerThread * 1024;
+  int16_t g0[kFovPerThread], g1[kFovPerThread];
+#pragma unroll
+  for (int k = 0; k < kFovPerThread; ++k) {
+    const int i = min(t + k * 1024, n_out - 1);
+    g0[k] = g[i];
+    g1[k] = g[i + 1];
+  }
   for (int x = t; x < size; x += 1024) flag[x] = 0;
   __syncthreads();
-  for (int i = t; i < n_out; i += 1024) {
+  AxisBox box[kFovPerThread];
+#pragma unroll
+  for (int k = 0; k < kFovPerThread; ++k) {
+    box[k] = sample_axis(centre, g1[k], g0[k], size, is_x);
+    if (t + k * 1024 < n_out && box[k].ok) {
+      flag[box[k].hi] = 1;
+      flag[box[k].lo] = 1;
+    }
+  }
+  for (int i = t + kFovPerThread * 1024; i < n_out; i += 1024) {  // longer axes: the slow way
     const AxisBox b = sample_axis(centre, g[i + 1], g[i], size, is_x);
     if (b.ok) {
       flag[b.hi] = 1;
@@ -527,20 +548,22 @@ __global__ __launch_bounds__(1024) void foveate_maps_kernel(const FovMaps m) {
     }
   }
   __syncthreads();
-  // rank the used entries: per-thread chunk counts, block scan, then the ranks
+  // rank the used entries: per-thread chunk counts, a wave scan + a scan over the 16 waves
   const int chunk = (size + 1023) / 1024;
   const int a = min(t * chunk, size), e = min(a + chunk, size);
   int cnt = 0;
   for (int x = a; x < e; ++x) cnt += flag[x];
-  part[t] = cnt;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if ((t & 63) >= off) incl += v;
   }
-  int run = part[t] - cnt;
+  if ((t & 63) == 63) part[t >> 6] = incl;
+  __syncthreads();
+  int wave_base = 0;
+  for (int w = 0; w < (t >> 6); ++w) wave_base += part[w];
+  int run = wave_base + incl - cnt;
   for (int x = a; x < e; ++x) {
     const int f = flag[x];
     const int rank = f ? run : -1;
@@ -549,6 +572,18 @@ __global__ __launch_bounds__(1024) void foveate_maps_kernel(const FovMaps m) {
     run += f;
   }
   __syncthreads();
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kFovPerThread; ++k) {
+      const int i = t + k * 1024;
+      if (i < n_out) {
+        ih[i] = box[k].ok ? flag[box[k].hi] : -1;
+        il[i] = box[k].ok ? flag[box[k].lo] : -1;
+        dw[i] = box[k].hi - box[k].lo;
+      }
+    }
+    return;
+  }
   for (int i = t; i < n_out; i += 1024) {
     const AxisBox b = sample_axis(centre, g[i + 1], g[i], size, is_x);
     ih[i] = b.ok ? flag[b.hi] : -1;
