@@ -135,6 +135,10 @@ _SIGNATURES = {
     "f360_tables_satdec_grid_axis": (c_int, [c_void_p, c_int, c_int]),
     "f360_tables_is_grid_axis": (c_int, [c_void_p, c_int, c_int]),
     "f360_tables_logpolar_axes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "f360_expand_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                 c_int, c_float, c_float]),
+    "f360_expand_logpolar": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                     c_int, c_int, c_float, c_float]),
     "f360_tables_interp_axis": (c_int, [c_void_p, c_int, c_int, c_int]),
     "f360_tables_yuv2rgb": (c_int, [c_void_p]),
 }
@@ -211,6 +215,18 @@ class Context:
         """The sws_scale of VideoDecoder::GetFrame (video_decoder.cc:222-224) on the device."""
         _check(lib().f360_yuv420p_to_rgb0(self._h, _p(dst), dst_linesize, _p(y), _p(u), _p(v),
                                           y_linesize, u_linesize, v_linesize, width, height))
+
+    def expand_rect(self, dst, dst_w, dst_h, dst_linesize, src, src_w, src_h, src_linesize,
+                    center_x, center_y) -> None:
+        """ExpandSampledFrameRectCPU (sat_decoder.cc:555-616) on the device."""
+        _check(lib().f360_expand_rect(self._h, _p(dst), dst_w, dst_h, dst_linesize, _p(src),
+                                      src_w, src_h, src_linesize, center_x, center_y))
+
+    def expand_logpolar(self, dst, dst_w, dst_h, dst_linesize, src, src_w, src_h, src_linesize,
+                        center_x, center_y) -> None:
+        """ExpandSampledFrameLogPolarCPU (image_sampler.cc:623-666) on the device."""
+        _check(lib().f360_expand_logpolar(self._h, _p(dst), dst_w, dst_h, dst_linesize, _p(src),
+                                          src_w, src_h, src_linesize, center_x, center_y))
 
     def profile_arm(self, calls: int) -> None:
         """Sample the next `calls` transform calls with HIP events around each kernel."""

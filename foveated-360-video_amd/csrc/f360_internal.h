@@ -78,6 +78,7 @@ enum KernelId {
   kFovMaps,
   kFovSample,
   kYuvToRgb,
+  kExpand,
   kKernelCount
 };
 struct ProfSpan {
@@ -102,6 +103,10 @@ struct f360_ctx {
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
+  // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
+  // log-polar scatter
+  int ex_w = 0, ex_h = 0, ex_tw = 0, ex_th = 0, ex_kind = -1;
+  f360::DevBuf ex_tables, ex_keys;
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;
   std::vector<f360::ProfSpan> prof_pending;

@@ -108,6 +108,8 @@ int f360_ctx_destroy(f360_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->enc.ws.release();
+  ctx->ex_tables.release();
+  ctx->ex_keys.release();
   for (const f360::ProfSpan &s : ctx->prof_pending) {
     (void)hipEventDestroy(s.a);
     (void)hipEventDestroy(s.b);
@@ -288,7 +290,8 @@ static const char *const kKernelNames[f360::kKernelCount] = {
     "sample_rect_kernel",       "interpolate_rect_kernel", "decode_kernel",
     "is_sample_rect_kernel",    "is_sample_logpolar_kernel",
     "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel",
-    "foveate_maps_kernel",      "sample_compact_kernel",  "yuv420p_to_rgb0_kernel"};
+    "foveate_maps_kernel",      "sample_compact_kernel",  "yuv420p_to_rgb0_kernel",
+    "expand_kernel"};
 
 int f360_kernel_count(void) { return f360::kKernelCount; }
 

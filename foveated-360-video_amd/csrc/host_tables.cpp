@@ -75,6 +75,34 @@ void build_yuv2rgb_consts(YuvConsts &k) {
   k.c0 = (int)(yb + (326 + 512) * cy + 0x8000);
 }
 
+// These two follow host C++ of the reference (not OpenCL C), so they use the C library's float
+// routines as that code does.
+void build_expand_axis(std::vector<int32_t> &d, int n_reduced, int n_full) {
+  d.resize((size_t)n_reduced);
+  const float lambda = n_full / (std::exp(1.0f) - 1);
+  for (int i = 0; i < n_reduced; ++i) {
+    const int u = i - n_reduced / 2;
+    const int a = u < 0 ? -u : u;
+    const int b = (int)(lambda * (std::exp(std::pow(2.0 * a / n_reduced, 4.0)) - 1));
+    d[(size_t)i] = (a > b ? a : b) * sgn(u);
+  }
+}
+
+void build_expand_logpolar_axes(std::vector<float> &radius, std::vector<double> &cs,
+                                std::vector<double> &sn, int src_w, int src_h) {
+  radius.resize((size_t)src_w);
+  cs.resize((size_t)src_h);
+  sn.resize((size_t)src_h);
+  const float alpha = 1.0f;
+  for (int i = 0; i < src_w; ++i)
+    radius[(size_t)i] = std::exp(10.0f * std::pow((float)i / src_w, alpha));
+  for (int j = 0; j < src_h; ++j) {
+    const double angle = (float)j / src_h * 2 * M_PI;
+    cs[(size_t)j] = std::cos(angle);
+    sn[(size_t)j] = std::sin(angle);
+  }
+}
+
 void build_satdec_grid_axis(std::vector<int16_t> &g, int n_out, int n_src) {
   g.resize((size_t)n_out + 1);
   const float lambda = lambda_of(n_src);

@@ -52,4 +52,13 @@ struct InterpAxisEntry {
 void build_interp_axis(std::vector<InterpAxisEntry> &t, int range, int n_full,
                        int n_reduced);
 
+// ExpandSampledFrameRectCPU (src/sat_decoder.cc:575-598), one axis: the offset from the gaze
+// centre at which reduced pixel i was sampled, max(|u|, (int)(lambda (exp(pow(2.0|u|/n, 4.0)) - 1)))
+// sgn(u) with u = i - n_reduced / 2, lambda = n_full / (expf(1) - 1) in float, the rest double.
+void build_expand_axis(std::vector<int32_t> &d, int n_reduced, int n_full);
+// ExpandSampledFrameLogPolarCPU (src/image_sampler.cc:646-651): radius per reduced column
+// (float: expf(10 * powf(i / w, 1))), cos / sin per reduced row (double, of a float angle * 2 * pi)
+void build_expand_logpolar_axes(std::vector<float> &radius, std::vector<double> &cs,
+                                std::vector<double> &sn, int src_w, int src_h);
+
 }  // namespace f360

@@ -262,6 +262,22 @@ int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_width,
                   int source_height, int source_linesize, float center_x,
                   float center_y);
 
+/* ---- "expand" debug views --------------------- */
+/* SATDecoder::ExpandSampledFrameRectCPU (src/sat_decoder.cc:555-616) and its copy
+ * ImageSampler::ExpandSampledFrameRectCPU (src/image_sampler.cc:358-419), on the device: every
+ * pixel of the reduced (source) frame is copied to the target pixel the log-rectilinear sampler
+ * took it from; 3 bytes per pixel, bytes per pixel = linesize / width on both sides; target
+ * pixels nothing lands on keep their value.  The reference has these on the CPU only. */
+int f360_expand_rect(f360_ctx *ctx, uint8_t *dst_dev, int dst_w, int dst_h, int dst_linesize,
+                     const uint8_t *src_dev, int src_w, int src_h, int src_linesize,
+                     float center_x, float center_y);
+/* ImageSampler::ExpandSampledFrameLogPolarCPU (src/image_sampler.cc:623-666): the log-polar
+ * counterpart.  Where several source pixels land on one target pixel the reference's loop order
+ * (columns outer, rows inner) decides; the result here is that of the sequential loop. */
+int f360_expand_logpolar(f360_ctx *ctx, uint8_t *dst_dev, int dst_w, int dst_h,
+                         int dst_linesize, const uint8_t *src_dev, int src_w, int src_h,
+                         int src_linesize, float center_x, float center_y);
+
 /* ---- host-only geometry tables (no device needed) -------------------------
  * The 1-D factors the kernels read instead of the reference's 2-D grids and
  * per-pixel transcendentals; exported so the host logic can be checked on a

@@ -42,6 +42,25 @@ class ImageSampler {
   }
   ~ImageSampler() { f360_is_destroy(impl); }
 
+  // The reference has these two views on the CPU only (ExpandSampledFrameRectCPU,
+  // src/image_sampler.cc:358-419; ExpandSampledFrameLogPolarCPU, :623-666; AVFrame arguments);
+  // same results on device buffers.
+  void ExpandSampledFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
+                                 int target_linesize, cl_mem cl_source_buffer, int source_width,
+                                 int source_height, int source_linesize, float center_x,
+                                 float center_y) {
+    Expand(false, cl_target_buffer, target_width, target_height, target_linesize,
+           cl_source_buffer, source_width, source_height, source_linesize, center_x, center_y);
+  }
+  void ExpandSampledFrameLogPolarGPU(cl_mem cl_target_buffer, int target_width,
+                                     int target_height, int target_linesize,
+                                     cl_mem cl_source_buffer, int source_width,
+                                     int source_height, int source_linesize, float center_x,
+                                     float center_y) {
+    Expand(true, cl_target_buffer, target_width, target_height, target_linesize,
+           cl_source_buffer, source_width, source_height, source_linesize, center_x, center_y);
+  }
+
   void InitializeGrid(int target_width, int target_height, int source_width, int source_height) {
     if (use_opencl)
       report("InitializeGrid", f360_is_initialize_grid(impl, target_width, target_height,
@@ -110,5 +129,23 @@ class ImageSampler {
            f360_is_logpolar_gaussian_blur(impl, static_cast<uint8_t *>(cl_target_buffer),
                                           target_width, target_height, target_linesize,
                                           static_cast<const uint8_t *>(cl_source_buffer)));
+  }
+
+ private:
+  void Expand(bool logpolar, cl_mem cl_target_buffer, int target_width, int target_height,
+              int target_linesize, cl_mem cl_source_buffer, int source_width, int source_height,
+              int source_linesize, float center_x, float center_y) {
+    if (!cl_manager) {
+      std::cerr << "[ImageSampler::ExpandSampledFrame] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    auto fn = logpolar ? f360_expand_logpolar : f360_expand_rect;
+    const int ret = fn(cl_manager->context.get(), static_cast<uint8_t *>(cl_target_buffer),
+                       target_width, target_height, target_linesize,
+                       static_cast<const uint8_t *>(cl_source_buffer), source_width,
+                       source_height, source_linesize, center_x, center_y);
+    if (ret != F360_OK)
+      std::cerr << "[ImageSampler::ExpandSampledFrame] kernel launch failed:" << ret << " "
+                << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 };

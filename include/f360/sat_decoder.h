@@ -117,6 +117,26 @@ class SATDecoder {
                 << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 
+  // The reference has this view on the CPU only (ExpandSampledFrameRectCPU,
+  // src/sat_decoder.cc:555-616, AVFrame arguments); same result on device buffers.
+  void ExpandSampledFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
+                                 int target_linesize, cl_mem cl_source_buffer, int source_width,
+                                 int source_height, int source_linesize, float center_x,
+                                 float center_y) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::ExpandSampledFrameRectGPU] Not initialized with OpenCL"
+                << std::endl;
+      return;
+    }
+    const int ret = f360_expand_rect(
+        cl_manager->context.get(), static_cast<uint8_t *>(cl_target_buffer), target_width,
+        target_height, target_linesize, static_cast<const uint8_t *>(cl_source_buffer),
+        source_width, source_height, source_linesize, center_x, center_y);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::ExpandSampledFrameRectGPU] kernel launch failed:" << ret << " "
+                << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
   // src/sat_decoder.cc:887-928
   void InterpolateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,
                                int target_linesize, cl_mem cl_source_buffer, int source_width,

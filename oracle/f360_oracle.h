@@ -112,6 +112,17 @@ void f360o_yuv420p_to_rgb0(uint8_t *dst, int dst_linesize, const uint8_t *y_plan
                            const uint8_t *v_plane, int v_linesize, int width, int height,
                            int model);
 
+/* --- "expand" debug views (f360_oracle_expand.c) --------------------------- */
+/* src/sat_decoder.cc:555-616 (== src/image_sampler.cc:358-419): reduced frame scattered back to
+ * where the log-rectilinear sampler took it from; untouched target pixels keep their value */
+void f360o_expand_rect(uint8_t *dst, int dst_w, int dst_h, int dst_linesize, const uint8_t *src,
+                       int src_w, int src_h, int src_linesize, float cx, float cy);
+/* src/image_sampler.cc:623-666: the log-polar counterpart (last writer in i-outer, j-inner order
+ * wins where several source pixels land on one target pixel) */
+void f360o_expand_logpolar(uint8_t *dst, int dst_w, int dst_h, int dst_linesize,
+                           const uint8_t *src, int src_w, int src_h, int src_linesize, float cx,
+                           float cy);
+
 /* --- whole hot path, used by bench.py's cpu_baseline leg ------------------ */
 /* SAT encode + log-rectilinear SAT sample of `frames` frames; frame k is an
  * LCG fill with seed seed0+k, gaze is the Lissajous of SURVEY.md 8d(2).

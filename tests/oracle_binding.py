@@ -43,6 +43,9 @@ def lib() -> ctypes.CDLL:
         L.f360o_satdec_interpolate_rect.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int,
                                                     c_int, c_float, c_float]
         L.f360o_satdec_decode.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int]
+        L.f360o_expand_rect.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                        c_int, c_float, c_float]
+        L.f360o_expand_logpolar.argtypes = L.f360o_expand_rect.argtypes
         L.f360o_yuv_to_rgb_pixel.argtypes = [c_int, c_int, c_int, c_int, c_void_p]
         L.f360o_yuv420p_to_rgb0.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                             c_void_p, c_int, c_int, c_int, c_int]
@@ -200,4 +203,12 @@ def yuv420p_to_rgb0(y, u, v, width, height, model, dst=None, dst_linesize=None) 
         dst = np.zeros((height, dst_linesize), dtype=np.uint8)
     lib().f360o_yuv420p_to_rgb0(_ptr(dst), dst_linesize, _ptr(y), y.shape[1], _ptr(u), u.shape[1],
                                 _ptr(v), v.shape[1], width, height, model)
+    return dst
+
+
+def expand(kind, dst, dst_w, dst_h, dst_linesize, src, src_w, src_h, src_linesize, cx, cy):
+    """kind: "rect" or "logpolar"; dst is modified in place (untouched pixels keep their value)."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    fn = lib().f360o_expand_rect if kind == "rect" else lib().f360o_expand_logpolar
+    fn(_ptr(dst), dst_w, dst_h, dst_linesize, _ptr(src), src_w, src_h, src_linesize, cx, cy)
     return dst

@@ -815,3 +815,22 @@ def test_yuv_argument_checks(f360, gpu_ctx):
     with pytest.raises(f360.F360Error):
         gpu_ctx.set_option("yuv.model", 2)
     a.free()
+
+
+# ------------------------------------------------------------------ "expand" debug views (8f-4)
+@pytest.mark.parametrize("kind", ["rect", "logpolar"])
+@pytest.mark.parametrize("w,h,rw,rh,dbpp,sbpp", [(256, 128, 144, 80, 4, 4), (1920, 1080, 1072, 608, 4, 4),
+                                                 (200, 100, 112, 64, 3, 4), (64, 32, 48, 32, 4, 3)])
+def test_expand_views_match_oracle(f360, gpu_ctx, oracle, kind, w, h, rw, rh, dbpp, sbpp):
+    red = oracle.lcg_frame(rw, rh, 77, bpp=sbpp)
+    src = gpu_ctx.upload(red)
+    dst = gpu_ctx.malloc(h * dbpp * w)
+    fn = gpu_ctx.expand_rect if kind == "rect" else gpu_ctx.expand_logpolar
+    for (cx, cy) in [(0.5, 0.5), (0.0, 0.0), (0.65, 0.75), (1.0, 0.1)]:
+        want = np.full((h, dbpp * w), 0x33, np.uint8)
+        oracle.expand(kind, want, w, h, dbpp * w, red, rw, rh, sbpp * rw, cx, cy)
+        dst.fill(0x33)
+        fn(dst.ptr, w, h, dbpp * w, src.ptr, rw, rh, sbpp * rw, cx, cy)
+        assert np.array_equal(dst.copy_to_host(np.uint8, (h, dbpp * w)), want), (kind, cx, cy)
+    src.free()
+    dst.free()

@@ -215,3 +215,32 @@ def test_interp_axis_table_properties(f360):
     inner = np.abs(d) <= w // 2
     assert (np.abs(dcalc[inner]) >= np.abs(d[inner])).all()
     assert (np.abs(dmin[inner]) <= np.abs(dcalc[inner])).all()
+
+
+def test_expand_rect_inverts_the_sampler_lattice(oracle):
+    """ExpandSampledFrameRectCPU scatters reduced pixel (i, j) to centre + f(u), f(v): the fovea
+    (unit steps) is copied verbatim, other target pixels keep their value."""
+    w, h = 256, 128
+    rw, rh = 144, 80
+    red = oracle.lcg_frame(rw, rh, 5)
+    dst = np.full((h, 4 * w), 0x42, np.uint8)
+    oracle.expand("rect", dst, w, h, 4 * w, red, rw, rh, 4 * rw, 0.5, 0.5)
+    img, src = dst.reshape(h, w, 4), red.reshape(rh, rw, 4)
+    touched = (img[:, :, :3] != 0x42).any(axis=2)
+    assert touched.sum() <= rw * rh and touched.sum() > rw * rh // 4
+    assert (img[:, :, 3] == 0x42).all()  # 3 bytes per pixel only
+    for d in (-3, 0, 2):  # fovea: offset d from the centre maps to offset d
+        assert np.array_equal(img[h // 2 + d, w // 2 + d, :3], src[rh // 2 + d, rw // 2 + d, :3])
+
+
+def test_expand_logpolar_last_writer_wins(oracle):
+    w, h = 128, 64
+    rw, rh = 80, 48
+    red = oracle.lcg_frame(rw, rh, 6)
+    dst = np.zeros((h, 4 * w), np.uint8)
+    oracle.expand("logpolar", dst, w, h, 4 * w, red, rw, rh, 4 * rw, 0.5, 0.5)
+    img, src = dst.reshape(h, w, 4), red.reshape(rh, rw, 4)
+    # column 0 has radius exp(0) = 1: at angle 0 it lands on (cx + 1, cy); the last row j whose
+    # angle still truncates to that pixel owns it, and later columns with radius < 2 overwrite it
+    assert img[h // 2, w // 2 + 1, :3].any()
+    assert (img[:, :, 3] == 0).all()
