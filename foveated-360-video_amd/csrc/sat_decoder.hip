@@ -892,6 +892,19 @@ __global__ __launch_bounds__(256) void interpolate_rect_kernel(
     return *reinterpret_cast<const uint32_t *>(srcb + byte_off);
   };
 
+  // The four neighbours of a pixel are fetched once per distinct (column pair, row pair): in the
+  // periphery several adjacent output columns (rows) map to the same pair of reduced columns
+  // (rows), so a column whose pair equals its left neighbour's copies it, and a row whose pair
+  // equals the previous row's keeps the registers.  The kernel is bound by the number of
+  // gathered lanes, not by bytes.
+  bool same_as_left[kInterpCols];
+  same_as_left[0] = false;
+#pragma unroll
+  for (int k = 1; k < kInterpCols; ++k)
+    same_as_left[k] = off_lo[k] == off_lo[k - 1] && off_hi[k] == off_hi[k - 1];
+  uint32_t tl[kInterpCols], tr[kInterpCols], bl[kInterpCols], br[kInterpCols];
+  int held_lo = -1, held_hi = -1;  // reduced rows the registers above hold
+
   const int y1 = min(y0 + rows, out_h);
   for (int y = y0; y < y1; ++y) {
     const InterpAxis ay = interp_axis(y, cyp, ty[y - cyp + range_y], false, out_h, src_h, src_h);
@@ -901,14 +914,28 @@ __global__ __launch_bounds__(256) void interpolate_rect_kernel(
       for (int k = 0; k < kInterpCols; ++k)
         out[k] = texel((uint32_t)ay.exact_idx * row_bytes + off_ex[k]) & 0x00ffffffu;
     } else {
-      const uint32_t r_lo = (uint32_t)ay.lo * row_bytes, r_hi = (uint32_t)ay.hi * row_bytes;
-      uint32_t tl[kInterpCols], tr[kInterpCols], bl[kInterpCols], br[kInterpCols];
+      if (ay.lo != held_lo || ay.hi != held_hi) {  // wave-uniform
+        const uint32_t r_lo = (uint32_t)ay.lo * row_bytes, r_hi = (uint32_t)ay.hi * row_bytes;
 #pragma unroll
-      for (int k = 0; k < kInterpCols; ++k) {
-        tl[k] = texel(r_lo + off_lo[k]);
-        tr[k] = texel(r_lo + off_hi[k]);
-        bl[k] = texel(r_hi + off_lo[k]);
-        br[k] = texel(r_hi + off_hi[k]);
+        for (int k = 0; k < kInterpCols; ++k) {
+          if (!same_as_left[k]) {
+            tl[k] = texel(r_lo + off_lo[k]);
+            tr[k] = texel(r_lo + off_hi[k]);
+            bl[k] = texel(r_hi + off_lo[k]);
+            br[k] = texel(r_hi + off_hi[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 1; k < kInterpCols; ++k) {
+          if (same_as_left[k]) {
+            tl[k] = tl[k - 1];
+            tr[k] = tr[k - 1];
+            bl[k] = bl[k - 1];
+            br[k] = br[k - 1];
+          }
+        }
+        held_lo = ay.lo;
+        held_hi = ay.hi;
       }
       // two pixels per packed-float instruction (v_pk_mul_f32 / v_pk_add_f32): the same IEEE
       // operations in the same order as the scalar form, so the results are unchanged
@@ -1423,7 +1450,7 @@ int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   // that a small frame still yields thousands of waves (each row is a chain of dependent loads)
   const long px = (long)target_width * target_height;
   const int rows = dec->ctx->opt_interp_rows > 0 ? dec->ctx->opt_interp_rows
-                   : px >= 16000000 ? 16 : px >= 6000000 ? 4 : 1;
+                   : px >= 16000000 ? 8 : px >= 6000000 ? 4 : 2;
   const dim3 grid((target_width + 64 * kInterpCols - 1) / (64 * kInterpCols),
                   (target_height + 4 * rows - 1) / (4 * rows));
   f360::KernelSpan span(dec->ctx, f360::kInterpolateRect,
