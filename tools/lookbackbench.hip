@@ -28,7 +28,7 @@ struct Args {
   uint32_t *error;
   uint32_t epoch;
   int use_fence;             // 1: normal memory + __threadfence(); 0: fine-grained memory, waitcnt only
-  int do_lookback;
+  int do_lookback;           // 0: none, 1: serial walk, 2: windowed (64 predecessors polled at once)
 };
 
 __device__ __forceinline__ uint32_t flag_load(const uint32_t *p) {
@@ -53,6 +53,36 @@ __device__ __forceinline__ void publish_fence(const Args &a) {
 }
 __device__ __forceinline__ void consume_fence(const Args &a) {
   if (a.use_fence) __threadfence();
+}
+
+// Windowed look-back: lane l polls the flag of predecessor `first - l * stride` (first, first -
+// stride, ... down to `last`), until a contiguous run of ready predecessors ends in one with
+// inclusive sums (or at the last one).  Returns how many predecessors to add (the nearest
+// `count - 1` by their aggregate, the farthest by `*inclusive ? inclusive : aggregate`).
+__device__ __forceinline__ int window_wait(const Args &a, const uint32_t *flags, long first,
+                                           long stride, int avail, bool *inclusive) {
+  const int lane = threadIdx.x & 63;
+  const int n = min(avail, 64);
+  for (int spin = 0; spin < kSpinLimit; ++spin) {
+    uint32_t st = kEmpty;
+    if (lane < n) {
+      const uint32_t v = flag_load(flags + (first - (long)lane * stride));
+      st = (v >> 2) == a.epoch ? (v & 3u) : kEmpty;
+    }
+    const unsigned long long inc = __ballot(st == kInclusive);
+    const unsigned long long rdy = __ballot(st >= kAggregate);
+    const int first_inc = inc ? __ffsll((long long)inc) - 1 : 64;
+    const int need = min(first_inc + 1, n);
+    const unsigned long long mask = need >= 64 ? ~0ull : ((1ull << need) - 1);
+    if ((rdy & mask) == mask) {
+      *inclusive = first_inc < n;
+      return need;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (lane == 0) atomicOr(a.error, 1u);
+  *inclusive = true;
+  return 0;
 }
 
 template <int TB>
@@ -107,6 +137,24 @@ __global__ __launch_bounds__(256) void single_pass_kernel(const Args a) {
       flag_store(a.hflag + t, a.epoch * 4 + kAggregate);
     }
     // phase C: vertical look-back
+    if (a.do_lookback == 2) {
+      int b_hi = band - 1;
+      while (b_hi >= 0) {
+        bool inc;
+        const int need = window_wait(a, a.vflag, (long)b_hi * a.nstrips + strip, a.nstrips, b_hi + 1, &inc);
+        if (need == 0) break;
+        for (int l = 0; l < need; ++l) {  // loads of one window are independent of each other
+          const size_t p = (size_t)(b_hi - l) * a.nstrips + strip;
+          const uint4 *v = reinterpret_cast<const uint4 *>(((inc && l == need - 1) ? a.colinc : a.colagg) + p * 768) + lane * 3;
+          const uint4 v0 = v[0], v1 = v[1], v2 = v[2];
+          cprefix[0] += v0.x; cprefix[1] += v0.y; cprefix[2] += v0.z; cprefix[3] += v0.w;
+          cprefix[4] += v1.x; cprefix[5] += v1.y; cprefix[6] += v1.z; cprefix[7] += v1.w;
+          cprefix[8] += v2.x; cprefix[9] += v2.y; cprefix[10] += v2.z; cprefix[11] += v2.w;
+        }
+        if (inc) break;
+        b_hi -= need;
+      }
+    } else
     for (int b = band - 1; b >= 0; --b) {
       const size_t p = (size_t)b * a.nstrips + strip;
       const uint32_t st = wait_flag(a, a.vflag + p, kAggregate);
@@ -127,6 +175,23 @@ __global__ __launch_bounds__(256) void single_pass_kernel(const Args a) {
       if (lane == 0) flag_store(a.vflag + t, a.epoch * 4 + kInclusive);
     }
     // horizontal look-back
+    if (a.do_lookback == 2) {
+      int s_hi = strip - 1;
+      while (s_hi >= 0) {
+        bool inc;
+        const int need = window_wait(a, a.hflag, (long)band * a.nstrips + s_hi, 1, s_hi + 1, &inc);
+        if (need == 0) break;
+        for (int l = 0; l < need; ++l) {
+          const size_t p = (size_t)band * a.nstrips + (s_hi - l);
+          if (lane < TB) {
+            const uint32_t *v = ((inc && l == need - 1) ? a.rowinc : a.rowagg) + p * 256 + lane * 3;
+            rprefix[0] += v[0]; rprefix[1] += v[1]; rprefix[2] += v[2];
+          }
+        }
+        if (inc) break;
+        s_hi -= need;
+      }
+    } else
     for (int s = strip - 1; s >= 0; --s) {
       const size_t p = (size_t)band * a.nstrips + s;
       const uint32_t st = wait_flag(a, a.hflag + p, kAggregate);
@@ -186,7 +251,8 @@ int run(int use_fence, int finegrained) {
   a.vflag = (uint32_t *)flags; a.hflag = a.vflag + ntiles; a.ticket = a.hflag + ntiles; a.error = a.ticket + 1;
   const dim3 grid((unsigned)((ntiles + 3) / 4));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int lb = 0; lb < 2; ++lb) {
+  for (int lb = 0; lb < 3; ++lb) {
+    if (use_fence && lb == 2) continue;
     a.do_lookback = lb;
     float best = 1e30f, sum = 0; const int reps = 12;
     for (int r = 0; r < reps + 2; ++r) {
