@@ -157,3 +157,57 @@ def test_random_image_sampler_and_gnomonic(f360, gpu_ctx, oracle):
         smp.close()
     assert bad_lp <= max(2, total_lp // 10000), (bad_lp, total_lp)
     assert bad_gn <= max(2, total_gn // 10000), (bad_gn, total_gn)
+
+
+def test_random_planar_sources(f360, gpu_ctx, oracle):
+    """Planar YUV 4:2:0: random sizes (width % 4, even height), plane paddings, both libswscale
+    models and tilings -- converter, table and fused foveation against the oracle."""
+    rng = np.random.default_rng(4242)
+    enc = f360.SATEncoder(gpu_ctx)
+    old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands", "yuv.model")}
+    try:
+        for case in range(30):
+            w, h = random_geometry(rng)
+            w, h = max(4, w // 4 * 4), max(2, h // 2 * 2)
+            model = int(rng.integers(0, 2))
+            gpu_ctx.set_option("yuv.model", model)
+            gpu_ctx.set_option("sat.band_rows", int(rng.choice([0, 16, 32, 64])))
+            gpu_ctx.set_option("sat.sb_bands", int(rng.choice([-1, 0, 1, 2, 3])))
+            ypad, cpad = int(rng.choice([0, 4, 8])), int(rng.choice([0, 2, 6]))
+            y = rng.integers(0, 256, (h, w + ypad), dtype=np.uint8)
+            u = rng.integers(0, 256, (h // 2, w // 2 + cpad), dtype=np.uint8)
+            v = rng.integers(0, 256, (h // 2, w // 2 + cpad), dtype=np.uint8)
+            if case % 5 == 0:
+                y[:] = 255
+            rgb0 = oracle.yuv420p_to_rgb0(y, u, v, w, h, model)
+            want_sat = oracle.sat_encode(rgb0, w, h, 4 * w)
+            dy, du, dv = gpu_ctx.upload(y), gpu_ctx.upload(u), gpu_ctx.upload(v)
+            rgb = gpu_ctx.malloc(w * h * 4)
+            sat = gpu_ctx.malloc(w * h * 12)
+            sat.fill(0xEE)
+            gpu_ctx.yuv420p_to_rgb0(rgb.ptr, 4 * w, dy.ptr, du.ptr, dv.ptr, y.shape[1], u.shape[1],
+                                    v.shape[1], w, h)
+            enc.EncodeFrameYUV420PGPU(sat.ptr, dy.ptr, du.ptr, dv.ptr, y.shape[1], u.shape[1],
+                                      v.shape[1], w, h)
+            assert np.array_equal(rgb.copy_to_host(np.uint8, (h, 4 * w)), rgb0), (case, w, h, model)
+            assert np.array_equal(sat.copy_to_host(np.uint32, (h, w, 3)), want_sat), (case, w, h, model)
+            if w >= 8 and h >= 8:
+                rw, rh = reduced(w), reduced(h)
+                dec = f360.SATDecoder(gpu_ctx)
+                dec.InitializeGrid(rw, rh, w, h)
+                grid = oracle.satdec_grid(rw, rh, w, h)
+                cx, cy = random_gaze(rng)
+                want = np.full((rh, 4 * rw), 0x5A, np.uint8)
+                oracle.satdec_sample_rect(want, rw, rh, 4 * rw, want_sat, w, h, grid, cx, cy)
+                red = gpu_ctx.malloc(rh * 4 * rw)
+                red.fill(0x5A)
+                dec.FoveateFrameRectYUV420PGPU(red.ptr, rw, rh, 4 * rw, dy.ptr, du.ptr, dv.ptr,
+                                               y.shape[1], u.shape[1], v.shape[1], w, h, cx, cy)
+                assert np.array_equal(red.copy_to_host(np.uint8, (rh, 4 * rw)), want), (case, w, h)
+                red.free()
+                dec.close()
+            for b in (dy, du, dv, rgb, sat):
+                b.free()
+    finally:
+        for k, v_ in old.items():
+            gpu_ctx.set_option(k, v_)
