@@ -91,7 +91,24 @@ int main(int argc, char **argv) {
       std::cerr << "Failed to copy frame to GPU" << std::endl;
       return EXIT_FAILURE;
     }
-    sat_encoder.EncodeFrameGPU(cl_sat_buffer(), cl_source_frame(), width, height, linesize);
+    if (mode == "planar_expand") {
+      // the decoder's yuv420p planes instead of the sws_scale'd RGB0 frame: Y, U, V are the
+      // first bytes of the synthetic buffer (tight rows), the RGB0 buffer is only the expand target
+      const size_t y_bytes = (size_t)width * height, c_bytes = y_bytes / 4;
+      cl::Buffer cl_y(cl_manager.context, CL_MEM_READ_ONLY, y_bytes);
+      cl::Buffer cl_u(cl_manager.context, CL_MEM_READ_ONLY, c_bytes);
+      cl::Buffer cl_v(cl_manager.context, CL_MEM_READ_ONLY, c_bytes);
+      const uint8_t *planes = rgb_frame.data();
+      cl::copy(cl_manager.command_queue, planes, planes + y_bytes, cl_y);
+      cl::copy(cl_manager.command_queue, planes + y_bytes, planes + y_bytes + c_bytes, cl_u);
+      cl::copy(cl_manager.command_queue, planes + y_bytes + c_bytes, planes + y_bytes + 2 * c_bytes,
+               cl_v);
+      sat_encoder.EncodeFrameYUV420PGPU(cl_sat_buffer(), cl_y(), cl_u(), cl_v(), width, width / 2,
+                                        width / 2, width, height);
+      clFinish(cl_manager.command_queue());  // the plane buffers go out of scope below
+    } else {
+      sat_encoder.EncodeFrameGPU(cl_sat_buffer(), cl_source_frame(), width, height, linesize);
+    }
     sat_decoder.SampleFrameRectGPU(cl_output_buffer(), reduced_width, reduced_height,
                                    rect_linesize, cl_sat_buffer(), source_codec_ctx, center_x,
                                    center_y);
@@ -99,6 +116,10 @@ int main(int argc, char **argv) {
       sat_decoder.InterpolateFrameRectGPU(cl_source_frame(), width, height, linesize,
                                           cl_output_buffer(), reduced_width, reduced_height,
                                           rect_linesize, center_x, center_y);
+    if (mode == "planar_expand")  // debug view: reduced pixels scattered back over the frame
+      sat_decoder.ExpandSampledFrameRectGPU(cl_source_frame(), width, height, linesize,
+                                            cl_output_buffer(), reduced_width, reduced_height,
+                                            rect_linesize, center_x, center_y);
     clFlush(cl_manager.command_queue());
     clFinish(cl_manager.command_queue());
     std::vector<uint8_t> out_rect(rect_frame.size());
@@ -109,7 +130,7 @@ int main(int argc, char **argv) {
       return EXIT_FAILURE;
     }
     digest_rect ^= fnv1a64(out_rect.data(), out_rect.size()) + frame;
-    if (mode == "foveate_no_encoding") {
+    if (mode == "foveate_no_encoding" || mode == "planar_expand") {
       ret = cl::copy(cl_manager.command_queue, cl_source_frame, rgb_frame.data(),
                      rgb_frame.data() + source_frame_size);
       digest_full ^= fnv1a64(rgb_frame.data(), rgb_frame.size()) + frame;

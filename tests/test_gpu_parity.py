@@ -834,3 +834,34 @@ def test_expand_views_match_oracle(f360, gpu_ctx, oracle, kind, w, h, rw, rh, db
         assert np.array_equal(dst.copy_to_host(np.uint8, (h, dbpp * w)), want), (kind, cx, cy)
     src.free()
     dst.free()
+
+
+def test_cpp_dropin_example_planar_and_expand(f360, gpu_ctx, oracle):
+    """The C++ classes' added entry points (EncodeFrameYUV420PGPU, ExpandSampledFrameRectGPU)
+    through the same example binary, against the oracle."""
+    import json
+    import subprocess
+    repo = os.path.dirname(HERE)
+    exe = os.path.join(repo, "examples", "run_satlogrectilinear_synth")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(repo, "examples")], check=True)
+    w, h = 640, 320
+    rw, rh = reduced(w), reduced(h)
+    out = subprocess.run([exe, "planar_expand", str(w), str(h), "1"], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    buf = oracle.lcg_frame(w, h, 12345).reshape(-1)  # the example's synthetic buffer
+    y = buf[:w * h].reshape(h, w)
+    u = buf[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)
+    v = buf[w * h + w * h // 4:w * h + w * h // 2].reshape(h // 2, w // 2)
+    rgb0 = oracle.yuv420p_to_rgb0(y, u, v, w, h, oracle.YUV_SWS_X86)
+    sat = oracle.sat_encode(rgb0, w, h, 4 * w)
+    red = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+    oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, oracle.satdec_grid(rw, rh, w, h),
+                              0.5, 0.5)
+    full = buf.reshape(h, 4 * w).copy()  # the expand target still holds the synthetic bytes
+    oracle.expand("rect", full, w, h, 4 * w, red, rw, rh, 4 * rw, 0.5, 0.5)
+    assert got["sat"] == f"{oracle.fnv1a64(sat):016x}"
+    assert got["rect"] == f"{oracle.fnv1a64(red):016x}"
+    assert got["full"] == f"{oracle.fnv1a64(full):016x}"
