@@ -102,6 +102,7 @@ struct f360_ctx {
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
+  int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
   // log-polar scatter
@@ -204,4 +205,7 @@ struct f360_image_sampler {
   // interpolate_logpolar tables (per source geometry)
   int iw = 0, ih = 0;
   f360::DevBuf irad_dev, icos_dev, isin_dev;  // float[iw], double[ih], double[ih]
+  // interpolate_logpolar: offset -> reduced-buffer coordinate table of one geometry
+  int lpt_w = 0, lpt_h = 0, lpt_sw = 0, lpt_sh = 0;
+  f360::DevBuf lpt_dev;
 };

@@ -250,6 +250,7 @@ static const OptionSlot kOptions[] = {
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
     {"yuv.model", &f360_ctx::opt_yuv_model},
+    {"is.lp_table", &f360_ctx::opt_lp_table},
 };
 
 int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {

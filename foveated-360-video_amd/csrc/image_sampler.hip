@@ -72,21 +72,12 @@ __global__ __launch_bounds__(256) void is_sample_logpolar_kernel(
 }
 
 // interpolate_logpolar_kernel, src/image_sampler_interpolate_kernel.cl:1-81
-__global__ __launch_bounds__(256) void is_interpolate_logpolar_kernel(
-    uint32_t *__restrict__ dst, int out_w, int out_h,
-    const uint32_t *__restrict__ src, int src_w, int src_h,
-    const float *__restrict__ rad, const double *__restrict__ cs,
-    const double *__restrict__ sn, float cxf, float cyf, int cxp, int cyp) {
-  const int x0 = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x0 >= out_w || y >= out_h) return;
-  const int rw = src_w, rh = src_h;
-  int x = x0;
-  if (x - cxp > out_w / 2)
-    x -= out_w;
-  else if (x - cxp < (-out_w) / 2)
-    x += out_w;
-  const int dx = x - cxp, dy = y - cyp;
+//
+// Step 1 of the kernel (:26-44), the reduced-buffer coordinates of an output pixel, depends on
+// the INTEGER offset (delta_x, delta_y) from the truncated gaze centre and on the geometry only
+// -- not on the gaze.  It is also where all the time goes (log, sqrt, atan, fmod, each evaluated
+// in double and rounded once: 306 us per 8K frame, 0.06 of the HBM roofline).
+__device__ __forceinline__ float2 logpolar_uv(int dx, int dy, int rw, int rh, int src_h) {
   float i_f = 0.0f;
   if (dx != 0 || dy != 0) {
     // pow(d, 2.0f) correctly rounded == one rounding of the exact product;
@@ -95,7 +86,6 @@ __global__ __launch_bounds__(256) void is_interpolate_logpolar_kernel(
     const float r2 = fx * fx + fy * fy;
     i_f = (float)rw * (cr_logf(sqrtf(r2)) / 10.0f);
   }
-  const int i = min(max((int)roundf(i_f), 0), rw - 1);
   float j_f;
   if (dx != 0) {
     j_f = (float)(((double)cr_atanf((float)dy / (float)dx) +
@@ -106,32 +96,124 @@ __global__ __launch_bounds__(256) void is_interpolate_logpolar_kernel(
     j_f = (float)((M_PI_2 + M_PI * (double)(dy < 0)) *
                   ((double)rh / (2.0 * M_PI)));
   }
-  const int j = min(max((int)roundf(j_f), 0), rh - 1);
-  const double radius = (double)rad[i];
-  const int calc_x = (int)((double)cxf + radius * cs[j]);
-  const int calc_y = (int)((double)cyf + radius * sn[j]);
-  uint32_t out;
-  if (calc_x == x && calc_y == y) {
-    out = src[(size_t)j * src_w + i] & 0x00ffffffu;
-  } else {
-    const int min_i = min(max((int)floorf(i_f), 0), src_w - 1);
-    const int min_j = (int)floorf(j_f + (float)src_h) % src_h;
-    const int max_i = min(max((int)ceilf(i_f), 0), src_w - 1);
-    const int max_j = (int)ceilf(j_f + (float)src_h) % src_h;
-    const uint32_t tl = src[(size_t)min_j * src_w + min_i];
-    const uint32_t tr = src[(size_t)min_j * src_w + max_i];
-    const uint32_t bl = src[(size_t)max_j * src_w + min_i];
-    const uint32_t br = src[(size_t)max_j * src_w + max_i];
-    const float ir = i_f - floorf(i_f), jr = j_f - floorf(j_f);
-    out = 0;
+  return make_float2(i_f, j_f);
+}
+
+// out of line: the un-warp kernel calls it only for offsets outside its table, and inlining the
+// double-precision polynomials eight times costs it a third of its occupancy
+__device__ __noinline__ float2 logpolar_uv_outlined(int dx, int dy, int rw, int rh, int src_h) {
+  return logpolar_uv(dx, dy, rw, rh, src_h);
+}
+
+// Hence a table over the offsets, built once per geometry and shared by every gaze:
+// uv[(dy + span_y) * pitch + (dx + span_x)], |dx| <= span_x = W/2 + 1, |dy| <= span_y = H
+// (every offset a gaze inside the frame can produce; others are computed directly).
+struct LogpolarTable {
+  const float2 *uv;
+  int span_x, span_y, pitch;
+};
+
+__global__ __launch_bounds__(256) void logpolar_table_kernel(float2 *__restrict__ uv, int span_x,
+                                                             int span_y, int pitch, int rw, int rh,
+                                                             int src_h) {
+  const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ix > 2 * span_x || iy > 2 * span_y) return;
+  uv[(size_t)iy * pitch + ix] = logpolar_uv(ix - span_x, iy - span_y, rw, rh, src_h);
+}
+
+// A thread owns kLpRows vertically adjacent output pixels and runs the kernel's dependent steps
+// (offset table -> radius / cos / sin tables -> texels) for all of them at once: four memory
+// round trips per kLpRows pixels instead of per pixel (one pixel per thread was a chain of round
+// trips in 460 k short-lived waves at 8K).
+constexpr int kLpRows = 4;
+
+// m % n for the kernel's (int)floor(j_float + source_height) % source_height: j_float is the
+// result of an fmod by source_height (or a quarter / three quarters of it), so m lies in
+// [n, 2n]; anything else takes the integer division
+__device__ __forceinline__ int mod_near(int m, int n) {
+  if (m >= 0 && m < 3 * n) return m - (m >= n ? n : 0) - (m >= 2 * n ? n : 0);
+  return m % n;
+}
+
+__global__ __launch_bounds__(256) void is_interpolate_logpolar_kernel(
+    uint32_t *__restrict__ dst, int out_w, int out_h,
+    const uint32_t *__restrict__ src, int src_w, int src_h,
+    const float *__restrict__ rad, const double *__restrict__ cs,
+    const double *__restrict__ sn, float cxf, float cyf, int cxp, int cyp,
+    const LogpolarTable table) {
+  const int x0 = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kLpRows;
+  if (x0 >= out_w || y0 >= out_h) return;
+  const int rw = src_w, rh = src_h;
+  int x = x0;
+  if (x - cxp > out_w / 2)
+    x -= out_w;
+  else if (x - cxp < (-out_w) / 2)
+    x += out_w;
+  const int dx = x - cxp;
+
+  float2 uv[kLpRows];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float l = mixf((float)((tl >> (8 * c)) & 0xffu), (float)((bl >> (8 * c)) & 0xffu), jr);
-      const float r = mixf((float)((tr >> (8 * c)) & 0xffu), (float)((br >> (8 * c)) & 0xffu), jr);
-      out |= ((uint32_t)(int)mixf(l, r, ir) & 0xffu) << (8 * c);
+  for (int k = 0; k < kLpRows; ++k) {
+    const int dy = min(y0 + k, out_h - 1) - cyp;
+    if (table.uv && abs(dx) <= table.span_x && abs(dy) <= table.span_y)
+      uv[k] = table.uv[(size_t)(dy + table.span_y) * table.pitch + (dx + table.span_x)];
+    else
+      uv[k] = logpolar_uv_outlined(dx, dy, rw, rh, src_h);
+  }
+  int ii[kLpRows], jj[kLpRows];
+  float radius[kLpRows];
+  double cj[kLpRows], sj[kLpRows];
+#pragma unroll
+  for (int k = 0; k < kLpRows; ++k) {
+    ii[k] = min(max((int)roundf(uv[k].x), 0), rw - 1);
+    jj[k] = min(max((int)roundf(uv[k].y), 0), rh - 1);
+    radius[k] = rad[ii[k]];
+    cj[k] = cs[jj[k]];
+    sj[k] = sn[jj[k]];
+  }
+  bool exact[kLpRows];
+  uint32_t tl[kLpRows], tr[kLpRows], bl[kLpRows], br[kLpRows];
+#pragma unroll
+  for (int k = 0; k < kLpRows; ++k) {
+    const int y = min(y0 + k, out_h - 1);
+    const int calc_x = (int)((double)cxf + (double)radius[k] * cj[k]);
+    const int calc_y = (int)((double)cyf + (double)radius[k] * sj[k]);
+    exact[k] = calc_x == x && calc_y == y;
+    if (exact[k]) {
+      tl[k] = src[(size_t)jj[k] * src_w + ii[k]];
+    } else {
+      const float i_f = uv[k].x, j_f = uv[k].y;
+      const int min_i = min(max((int)floorf(i_f), 0), src_w - 1);
+      const int min_j = mod_near((int)floorf(j_f + (float)src_h), src_h);
+      const int max_i = min(max((int)ceilf(i_f), 0), src_w - 1);
+      const int max_j = mod_near((int)ceilf(j_f + (float)src_h), src_h);
+      tl[k] = src[(size_t)min_j * src_w + min_i];
+      tr[k] = src[(size_t)min_j * src_w + max_i];
+      bl[k] = src[(size_t)max_j * src_w + min_i];
+      br[k] = src[(size_t)max_j * src_w + max_i];
     }
   }
-  dst[(size_t)y * out_w + x0] = out;
+#pragma unroll
+  for (int k = 0; k < kLpRows; ++k) {
+    if (y0 + k >= out_h) break;
+    uint32_t out;
+    if (exact[k]) {
+      out = tl[k] & 0x00ffffffu;
+    } else {
+      const float i_f = uv[k].x, j_f = uv[k].y;
+      const float ir = i_f - floorf(i_f), jr = j_f - floorf(j_f);
+      out = 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float l = mixf((float)((tl[k] >> (8 * c)) & 0xffu), (float)((bl[k] >> (8 * c)) & 0xffu), jr);
+        const float r = mixf((float)((tr[k] >> (8 * c)) & 0xffu), (float)((br[k] >> (8 * c)) & 0xffu), jr);
+        out |= ((uint32_t)(int)mixf(l, r, ir) & 0xffu) << (8 * c);
+      }
+    }
+    dst[(size_t)(y0 + k) * out_w + x0] = out;
+  }
 }
 
 // logpolar_gaussian_blur_kernel, src/image_sampler_sample_logpolar_kernel.cl:88-142
@@ -199,6 +281,7 @@ int f360_is_destroy(f360_image_sampler *is) {
   is->irad_dev.release();
   is->icos_dev.release();
   is->isin_dev.release();
+  is->lpt_dev.release();
   delete is;
   return F360_OK;
 }
@@ -398,16 +481,41 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
     is->iw = source_width;
     is->ih = source_height;
   }
+  // the offset -> (i, j) table of this geometry ("is.lp_table", up to 1 GiB; 472 MB at 8K)
+  LogpolarTable table{nullptr, target_width / 2 + 1, target_height, 0};
+  table.pitch = 2 * table.span_x + 1;
+  const size_t table_bytes = (size_t)(2 * table.span_y + 1) * table.pitch * sizeof(float2);
+  if (is->ctx->opt_lp_table && table_bytes <= ((size_t)1 << 30)) {
+    if (is->lpt_w != target_width || is->lpt_h != target_height || is->lpt_sw != source_width ||
+        is->lpt_sh != source_height || !is->lpt_dev.p) {
+      F360_HIP_TRY(hipSetDevice(is->ctx->device));
+      F360_HIP_TRY(hipStreamSynchronize(is->ctx->stream));  // earlier calls may read the old one
+      int st = is->lpt_dev.reserve(table_bytes);
+      if (st != F360_OK) return st;
+      const dim3 tgrid((table.pitch + 63) / 64, (2 * table.span_y + 1 + 3) / 4);
+      hipLaunchKernelGGL(logpolar_table_kernel, tgrid, dim3(256), 0, is->ctx->stream,
+                         is->lpt_dev.as<float2>(), table.span_x, table.span_y, table.pitch,
+                         source_width, source_height, source_height);
+      F360_HIP_TRY(hipGetLastError());
+      is->lpt_w = target_width;
+      is->lpt_h = target_height;
+      is->lpt_sw = source_width;
+      is->lpt_sh = source_height;
+    }
+    table.uv = is->lpt_dev.as<float2>();
+  }
   const float cxf = center_x * (float)target_width;
   const float cyf = center_y * (float)target_height;
-  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  const dim3 grid((target_width + 63) / 64, (target_height + 4 * kLpRows - 1) / (4 * kLpRows));
+  f360::KernelSpan span(is->ctx, f360::kIsInterpolateLogpolar,
+                        f360::take_profile_slot(is->ctx));
   hipLaunchKernelGGL(is_interpolate_logpolar_kernel, grid, dim3(256), 0,
                      is->ctx->stream, reinterpret_cast<uint32_t *>(target_dev),
                      target_width, target_height,
                      reinterpret_cast<const uint32_t *>(source_dev), source_width,
                      source_height, is->irad_dev.as<float>(),
                      is->icos_dev.as<double>(), is->isin_dev.as<double>(), cxf, cyf,
-                     (int)cxf, (int)cyf);
+                     (int)cxf, (int)cyf, table);
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

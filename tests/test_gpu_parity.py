@@ -865,3 +865,27 @@ def test_cpp_dropin_example_planar_and_expand(f360, gpu_ctx, oracle):
     assert got["sat"] == f"{oracle.fnv1a64(sat):016x}"
     assert got["rect"] == f"{oracle.fnv1a64(red):016x}"
     assert got["full"] == f"{oracle.fnv1a64(full):016x}"
+
+
+@pytest.mark.parametrize("w,h", [(256, 128), (1920, 1080)])
+def test_logpolar_table_equals_direct_evaluation(f360, gpu_ctx, oracle, w, h):
+    """The per-geometry inverse-map table ("is.lp_table") is an optimisation only: with and
+    without it the un-warp writes the same bytes, for gazes inside and outside the frame (the
+    latter leave the table's offset range and are computed directly)."""
+    rw, rh = reduced(w), reduced(h)
+    red = gpu_ctx.upload(oracle.lcg_frame(rw, rh, 58))
+    a, b = gpu_ctx.malloc(w * h * 4), gpu_ctx.malloc(w * h * 4)
+    smp = f360.ImageSampler(gpu_ctx)
+    try:
+        for (cx, cy) in GAZES + EXTRA_GAZES + [(3.5, -2.25)]:
+            gpu_ctx.set_option("is.lp_table", 1)
+            smp.InterpolateFrameLogPolarGPU(a.ptr, w, h, 4 * w, red.ptr, rw, rh, 4 * rw, cx, cy)
+            gpu_ctx.set_option("is.lp_table", 0)
+            smp.InterpolateFrameLogPolarGPU(b.ptr, w, h, 4 * w, red.ptr, rw, rh, 4 * rw, cx, cy)
+            assert np.array_equal(a.copy_to_host(np.uint8, (h, 4 * w)),
+                                  b.copy_to_host(np.uint8, (h, 4 * w))), (cx, cy)
+    finally:
+        gpu_ctx.set_option("is.lp_table", 1)
+    for buf in (red, a, b):
+        buf.free()
+    smp.close()
