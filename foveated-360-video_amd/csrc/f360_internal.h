@@ -103,11 +103,15 @@ struct f360_ctx {
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
+  int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
   // log-polar scatter
   int ex_w = 0, ex_h = 0, ex_tw = 0, ex_th = 0, ex_kind = -1;
   f360::DevBuf ex_tables, ex_keys;
+  // gnomonic remap: view-independent per-pixel terms of one target geometry (projections.hip)
+  int gn_w = 0, gn_h = 0;
+  f360::DevBuf gn_table;
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;
   std::vector<f360::ProfSpan> prof_pending;

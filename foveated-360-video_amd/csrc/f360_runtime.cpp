@@ -109,6 +109,7 @@ int f360_ctx_destroy(f360_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->enc.ws.release();
   ctx->ex_tables.release();
+  ctx->gn_table.release();
   ctx->ex_keys.release();
   for (const f360::ProfSpan &s : ctx->prof_pending) {
     (void)hipEventDestroy(s.a);
@@ -250,6 +251,7 @@ static const OptionSlot kOptions[] = {
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
     {"yuv.model", &f360_ctx::opt_yuv_model},
+    {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"is.lp_table", &f360_ctx::opt_lp_table},
 };
 

@@ -21,18 +21,58 @@ __device__ __forceinline__ float cr_atan2f(float y, float x) {
   return (float)atan2((double)y, (double)x);
 }
 
-__global__ __launch_bounds__(256) void gnomonic_kernel(
-    uint32_t *__restrict__ dst, int dst_w, int dst_h,
-    const uint32_t *__restrict__ src, int src_w, int src_h, float lambda0,
-    float sp1, float cp1) {
+// What the kernel computes from the target pixel alone (:21-24,29-30 and the sin / cos of c in
+// :31-34): screen coordinates, rho, sin(atan(rho)), cos(atan(rho)).  Three of the five
+// transcendentals per pixel do not depend on the view centre, so they are tabulated once per
+// target geometry ("gnomonic.table") with this very code and read back every frame.
+struct GnomonicPixel {
+  float x, y, rho, sc, cc;
+};
+__device__ __forceinline__ GnomonicPixel gnomonic_pixel(int i, int j, int dst_w, int dst_h) {
+  GnomonicPixel p;
+  p.x = 6.0f * ((float)i / (float)dst_w - 0.5f);  // scale = (6, 3)
+  p.y = 3.0f * ((float)j / (float)dst_h - 0.5f);
+  p.rho = sqrtf(p.x * p.x + p.y * p.y);
+  const float c = cr_atanf(p.rho);
+  p.sc = cr_sinf(c);
+  p.cc = cr_cosf(c);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void gnomonic_table_kernel(float *__restrict__ table, int dst_w,
+                                                            int dst_h) {
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= dst_w || j >= dst_h) return;
-  const float x = 6.0f * ((float)i / (float)dst_w - 0.5f);  // scale = (6, 3)
-  const float y = 3.0f * ((float)j / (float)dst_h - 0.5f);
-  const float rho = sqrtf(x * x + y * y);
-  const float c = cr_atanf(rho);
-  const float sc = cr_sinf(c), cc = cr_cosf(c);
+  const GnomonicPixel p = gnomonic_pixel(i, j, dst_w, dst_h);
+  // planar layout: five planes of dst_w * dst_h floats, so that every read is coalesced
+  const size_t n = (size_t)dst_w * dst_h, at = (size_t)j * dst_w + i;
+  table[at] = p.x;
+  table[n + at] = p.y;
+  table[2 * n + at] = p.rho;
+  table[3 * n + at] = p.sc;
+  table[4 * n + at] = p.cc;
+}
+
+__global__ __launch_bounds__(256) void gnomonic_kernel(
+    uint32_t *__restrict__ dst, int dst_w, int dst_h,
+    const uint32_t *__restrict__ src, int src_w, int src_h, float lambda0,
+    float sp1, float cp1, const float *__restrict__ table) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= dst_w || j >= dst_h) return;
+  GnomonicPixel p;
+  if (table) {
+    const size_t n = (size_t)dst_w * dst_h, at = (size_t)j * dst_w + i;
+    p.x = table[at];
+    p.y = table[n + at];
+    p.rho = table[2 * n + at];
+    p.sc = table[3 * n + at];
+    p.cc = table[4 * n + at];
+  } else {
+    p = gnomonic_pixel(i, j, dst_w, dst_h);
+  }
+  const float x = p.x, y = p.y, rho = p.rho, sc = p.sc, cc = p.cc;
   float phi = cr_asinf(cc * sp1 + (y * sc * cp1) / rho);
   float lam = lambda0 + cr_atan2f(x * sc, rho * cp1 * cc - y * sp1 * sc);
   phi = (float)fmod((double)phi + F360_PI_2 + 10 * F360_PI, 2 * F360_PI);
@@ -72,10 +112,27 @@ extern "C" int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_widt
   const float sp1 = (float)std::sin((double)phi1);
   const float cp1 = (float)std::cos((double)phi1);
   const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  const float *table = nullptr;
+  const size_t table_bytes = (size_t)target_width * target_height * 5 * sizeof(float);
+  if (ctx->opt_gnomonic_table && table_bytes <= ((size_t)1 << 30)) {
+    if (ctx->gn_w != target_width || ctx->gn_h != target_height || !ctx->gn_table.p) {
+      F360_HIP_TRY(hipSetDevice(ctx->device));
+      F360_HIP_TRY(hipStreamSynchronize(ctx->stream));  // earlier calls may read the old table
+      int st = ctx->gn_table.reserve(table_bytes);
+      if (st != F360_OK) return st;
+      hipLaunchKernelGGL(gnomonic_table_kernel, grid, dim3(256), 0, ctx->stream,
+                         ctx->gn_table.as<float>(), target_width, target_height);
+      F360_HIP_TRY(hipGetLastError());
+      ctx->gn_w = target_width;
+      ctx->gn_h = target_height;
+    }
+    table = ctx->gn_table.as<float>();
+  }
+  f360::KernelSpan span(ctx, f360::kGnomonic, f360::take_profile_slot(ctx));
   hipLaunchKernelGGL(gnomonic_kernel, grid, dim3(256), 0, ctx->stream,
                      reinterpret_cast<uint32_t *>(target_dev), target_width,
                      target_height, reinterpret_cast<const uint32_t *>(source_dev),
-                     source_width, source_height, lambda0, sp1, cp1);
+                     source_width, source_height, lambda0, sp1, cp1, table);
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

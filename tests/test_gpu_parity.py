@@ -889,3 +889,23 @@ def test_logpolar_table_equals_direct_evaluation(f360, gpu_ctx, oracle, w, h):
     for buf in (red, a, b):
         buf.free()
     smp.close()
+
+
+def test_gnomonic_table_equals_direct_evaluation(f360, gpu_ctx, oracle):
+    """"gnomonic.table" only moves the view-independent terms into a per-geometry table."""
+    w, h, tw, th = 1920, 1080, 960, 540
+    src = gpu_ctx.upload(oracle.lcg_frame(w, h, 41))
+    a, b = gpu_ctx.malloc(tw * th * 4), gpu_ctx.malloc(tw * th * 4)
+    proj = f360.Projections(gpu_ctx)
+    try:
+        for (cx, cy) in GAZES + EXTRA_GAZES:
+            gpu_ctx.set_option("gnomonic.table", 1)
+            proj.GnomonicProjection(a.ptr, tw, th, 4 * tw, src.ptr, w, h, 4 * w, cx, cy)
+            gpu_ctx.set_option("gnomonic.table", 0)
+            proj.GnomonicProjection(b.ptr, tw, th, 4 * tw, src.ptr, w, h, 4 * w, cx, cy)
+            assert np.array_equal(a.copy_to_host(np.uint8, (th, 4 * tw)),
+                                  b.copy_to_host(np.uint8, (th, 4 * tw))), (cx, cy)
+    finally:
+        gpu_ctx.set_option("gnomonic.table", 1)
+    for buf in (src, a, b):
+        buf.free()
