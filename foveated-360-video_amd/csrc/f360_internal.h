@@ -104,6 +104,7 @@ struct f360_ctx {
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table
+  int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
   // log-polar scatter
@@ -163,10 +164,12 @@ inline bool take_profile_slot(f360_ctx *ctx) {
 
 namespace f360 {
 // Fused foveation: what the table writer emits instead of the full table.
+struct FovMaps;
 struct SatEmit {
   const int *xmap, *ymap;
   uint32_t *corners;
   int corner_stride;
+  const FovMaps *maps;  // non-null: the reducer's launch also computes the lattice maps
 };
 // `yuv` non-null: the pixels come from three planes (src_dev / linesize unused)
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,

@@ -251,6 +251,7 @@ static const OptionSlot kOptions[] = {
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
     {"yuv.model", &f360_ctx::opt_yuv_model},
+    {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"is.lp_table", &f360_ctx::opt_lp_table},
 };

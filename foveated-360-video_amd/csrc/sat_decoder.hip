@@ -15,37 +15,14 @@
 #include <cstring>
 
 #include "f360_internal.h"
+#include "fov_maps.h"
 #include "host_tables.h"
 
 namespace {
 
-// ---------------------------------------------------------------------------
-// One axis of sample_rect_kernel (src/sat_decoder_sample_rect_kernel.cl
-// :168-204): box corner `hi`, its lower partner `lo`, and whether the pixel is
-// processed at all as far as this axis is concerned.
-struct AxisBox {
-  int hi, lo;
-  bool ok;
-};
-
-__device__ __forceinline__ AxisBox sample_axis(int centre, int d_hi, int d_lo,
-                                               int size, bool wraps) {
-  int hi = centre + d_hi, lo = centre + d_lo;
-  if (wraps) {  // only x wraps (:181-187); the y wrap is commented out
-    if (hi >= size && lo >= size) {
-      hi -= size;
-      lo -= size;
-    } else if (hi < 0 && lo < 0) {
-      hi += size;
-      lo += size;
-    }
-  }
-  AxisBox b;
-  b.ok = (hi >= 0 && hi < size) || (lo >= 0 && lo < size);
-  b.hi = min(max(hi, 1), size - 1);
-  b.lo = min(max(lo, 0), b.hi - 1);
-  return b;
-}
+using f360::AxisBox;
+using f360::FovMaps;
+using f360::sample_axis;  // one axis of sample_rect_kernel's box rule (fov_maps.h)
 
 __device__ __forceinline__ uint3 load_sat3(const uint32_t *sat, size_t texel) {
   const uint32_t *p = sat + texel * 3;
@@ -496,100 +473,13 @@ __global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArg
 // that gaze samples are ever read.  foveate_maps_kernel numbers those rows and columns, the table
 // writer (sat_encode.hip, STORE == 2) emits just those entries into a compact array, and
 // sample_compact_kernel forms the box means from it -- the same integers as encode + sample.
-struct FovMaps {
-  const int16_t *gx, *gy;
-  int cxp, cyp, src_w, src_h, out_w, out_h;
-  int *xmap, *ymap;          // source column / row -> compact index or -1
-  int *ihx, *ilx, *dxw;      // per reduced column: compact index of hi / lo corner, box width
-  int *ihy, *ily, *dyw;      // per reduced row
-};
-
-constexpr int kFovLdsEntries = 16384;  // axis lengths up to this are ranked in LDS
-
-constexpr int kFovPerThread = 8;  // boxes a thread keeps in registers (axes up to 8192 outputs)
-
-__global__ __launch_bounds__(1024) void foveate_maps_kernel(const FovMaps m) {
-  __shared__ int part[16];
-  __shared__ int lflag[kFovLdsEntries];
-  const bool is_x = blockIdx.x == 0;
-  const int size = is_x ? m.src_w : m.src_h, n_out = is_x ? m.out_w : m.out_h;
-  const int16_t *g = is_x ? m.gx : m.gy;
-  const int centre = is_x ? m.cxp : m.cyp;
-  int *map = is_x ? m.xmap : m.ymap;
-  int *ih = is_x ? m.ihx : m.ihy, *il = is_x ? m.ilx : m.ily, *dw = is_x ? m.dxw : m.dyw;
-  int *flag = size <= kFovLdsEntries ? lflag : map;  // LDS when it fits, else in place
-  const int t = threadIdx.x;
-  // this thread's boxes: all grid loads are issued before anything depends on them, and the
-  // boxes stay in registers for the last phase (the kernel is a chain of round trips otherwise)
-  const bool in_regs = n_out <= kFovPerThread * 1024;
-  int16_t g0[kFovPerThread], g1[kFovPerThread];
-#pragma unroll
-  for (int k = 0; k < kFovPerThread; ++k) {
-    const int i = min(t + k * 1024, n_out - 1);
-    g0[k] = g[i];
-    g1[k] = g[i + 1];
-  }
-  for (int x = t; x < size; x += 1024) flag[x] = 0;
-  __syncthreads();
-  AxisBox box[kFovPerThread];
-#pragma unroll
-  for (int k = 0; k < kFovPerThread; ++k) {
-    box[k] = sample_axis(centre, g1[k], g0[k], size, is_x);
-    if (t + k * 1024 < n_out && box[k].ok) {
-      flag[box[k].hi] = 1;
-      flag[box[k].lo] = 1;
-    }
-  }
-  for (int i = t + kFovPerThread * 1024; i < n_out; i += 1024) {  // longer axes: the slow way
-    const AxisBox b = sample_axis(centre, g[i + 1], g[i], size, is_x);
-    if (b.ok) {
-      flag[b.hi] = 1;
-      flag[b.lo] = 1;
-    }
-  }
-  __syncthreads();
-  // rank the used entries: per-thread chunk counts, a wave scan + a scan over the 16 waves
-  const int chunk = (size + 1023) / 1024;
-  const int a = min(t * chunk, size), e = min(a + chunk, size);
-  int cnt = 0;
-  for (int x = a; x < e; ++x) cnt += flag[x];
-  int incl = cnt;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
-    if ((t & 63) >= off) incl += v;
-  }
-  if ((t & 63) == 63) part[t >> 6] = incl;
-  __syncthreads();
-  int wave_base = 0;
-  for (int w = 0; w < (t >> 6); ++w) wave_base += part[w];
-  int run = wave_base + incl - cnt;
-  for (int x = a; x < e; ++x) {
-    const int f = flag[x];
-    const int rank = f ? run : -1;
-    flag[x] = rank;
-    if (flag != map) map[x] = rank;
-    run += f;
-  }
-  __syncthreads();
-  if (in_regs) {
-#pragma unroll
-    for (int k = 0; k < kFovPerThread; ++k) {
-      const int i = t + k * 1024;
-      if (i < n_out) {
-        ih[i] = box[k].ok ? flag[box[k].hi] : -1;
-        il[i] = box[k].ok ? flag[box[k].lo] : -1;
-        dw[i] = box[k].hi - box[k].lo;
-      }
-    }
-    return;
-  }
-  for (int i = t; i < n_out; i += 1024) {
-    const AxisBox b = sample_axis(centre, g[i + 1], g[i], size, is_x);
-    ih[i] = b.ok ? flag[b.hi] : -1;
-    il[i] = b.ok ? flag[b.lo] : -1;
-    dw[i] = b.hi - b.lo;
-  }
+// The lattice maps as a kernel of their own (two workgroups, one per axis).  Normally they run as
+// two extra workgroups of the reducer's launch instead ("fov.piggyback", sat_encode.hip).
+__global__ __launch_bounds__(f360::kFovThreads) void foveate_maps_kernel(const FovMaps m) {
+  __shared__ uint8_t flags[f360::kFovLdsEntries];
+  __shared__ int16_t ranks[f360::kFovLdsEntries];
+  __shared__ int part[4];
+  f360::fov_maps_axis(m, (int)blockIdx.x, flags, ranks, part);
 }
 
 // The walker on the compact corner array: a box is (ih, il) in compact indices instead of
@@ -1344,12 +1234,14 @@ int foveate_rect_impl(f360_sat_decoder *dec, uint8_t *target_dev, int target_wid
   m.ily = w;   w += target_height;
   m.dyw = w;
   const bool prof = f360::take_profile_slot(ctx);
-  {
+  const bool piggyback = ctx->opt_fov_piggyback != 0;
+  if (!piggyback) {
     f360::KernelSpan span(ctx, f360::kFovMaps, prof);
-    hipLaunchKernelGGL(foveate_maps_kernel, dim3(2), dim3(1024), 0, ctx->stream, m);
+    hipLaunchKernelGGL(foveate_maps_kernel, dim3(2), dim3(f360::kFovThreads), 0, ctx->stream, m);
   }
   if (prof) ctx->prof_armed += 1;  // the encode below belongs to the same sampled call
-  f360::SatEmit emit{m.xmap, m.ymap, dec->fov_corners.as<uint32_t>(), cap_x};
+  f360::SatEmit emit{m.xmap, m.ymap, dec->fov_corners.as<uint32_t>(), cap_x,
+                     piggyback ? &m : nullptr};
   int st = f360::sat_encode_impl(ctx, nullptr, source_dev, source_width, source_height,
                                  source_linesize, &emit, yuv);
   if (st != F360_OK) return st;

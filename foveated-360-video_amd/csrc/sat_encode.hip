@@ -23,6 +23,7 @@
 //   Total HBM traffic ~20.6 B/px against 16 B/px compulsory (the reference's
 //   three passes move 64 B/px).
 #include "f360_internal.h"
+#include "fov_maps.h"
 #include "host_tables.h"
 
 namespace {
@@ -125,6 +126,10 @@ struct EncodeArgs {
   // SRC >= kSrcYuvSwsC: the three planes and the conversion constants
   f360::YuvPlanes yuv;
   f360::YuvConsts k;
+  // fused foveation: workgroups past `reduce_blocks` of the reducer's grid compute the lattice
+  // maps (one per axis) while the others reduce
+  int reduce_blocks, has_maps;
+  f360::FovMaps maps;
 };
 
 // kRowUnroll rows of a lane's four pixels as loaded; planar sources convert at use, so that
@@ -343,6 +348,13 @@ template <int SRC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
     const EncodeArgs a) {
   __shared__ uint32_t rowsum_stage[kWavesPerBlock * 64 * 3];  // one band of row sums per wave
+  if ((int)blockIdx.x >= a.reduce_blocks) {  // only when a.has_maps: see fov_maps.h
+    __shared__ uint8_t fov_flags[f360::kFovLdsEntries];
+    __shared__ int16_t fov_ranks[f360::kFovLdsEntries];
+    __shared__ int fov_part[4];
+    f360::fov_maps_axis(a.maps, (int)blockIdx.x - a.reduce_blocks, fov_flags, fov_ranks, fov_part);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const uint32_t rows_lds = (uint32_t)reinterpret_cast<uintptr_t>(rowsum_stage) +
                             (uint32_t)(threadIdx.x >> 6) * 64 * 3 * 4;
@@ -773,6 +785,9 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   a.ymap = emit ? emit->ymap : nullptr;
   a.corners = emit ? emit->corners : nullptr;
   a.corner_stride = emit ? emit->corner_stride : 0;
+  a.has_maps = emit && emit->maps ? 1 : 0;
+  if (a.has_maps) a.maps = *emit->maps;
+  else a.maps = FovMaps{};
   a.yuv = yuv ? *yuv : YuvPlanes{nullptr, nullptr, nullptr, 0, 0, 0};
   if (yuv)
     build_yuv2rgb_consts(a.k);
@@ -785,7 +800,9 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                    (emit || ((uintptr_t)sat_dev % 16) == 0);
   const int yuv_src = !yuv ? 0 : ctx->opt_yuv_model == 1 ? kSrcYuvSwsX86 : kSrcYuvSwsC;
   const dim3 block(64 * kWavesPerBlock);
-  const int blocks1 = (p.nstrips * p.nsb + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int reduce_blocks = (p.nstrips * p.nsb + kWavesPerBlock - 1) / kWavesPerBlock;
+  a.reduce_blocks = reduce_blocks;
+  const int blocks1 = reduce_blocks + (a.has_maps ? 2 : 0);
 
   {
     f360::KernelSpan span(ctx, f360::kSatReduce, prof);
