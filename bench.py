@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="FoveateFrameRectGPU (encode + sample without writing the table) instead "
                          "of the two reference calls")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the short untimed-region measurements of the fused / planar variants")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (invalid as a measurement)")
     args = ap.parse_args()
@@ -295,6 +297,34 @@ def main():
             "path_hbm_frac": round(path_bytes * (total_px / (w * h)) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "kernels": kernels,
         }
+        if world == 1 and not args.no_variants and not args.fused and not yuv:
+            # Outside the timed region, for information: the same frames through the fused call
+            # (same bytes out, no table) and from planar YUV 4:2:0; a few steps each.
+            def run_variant(call, nsteps=5):
+                for k in range(B):
+                    call(k)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(nsteps):
+                    for k in range(B):
+                        call(k)
+                torch.cuda.synchronize(dev)
+                return round(nsteps * B * w * h / 1e6 / (time.perf_counter() - t1), 1)
+            variants = {"fused_rgb0": run_variant(lambda k: decs[0].FoveateFrameRectGPU(
+                red_ptr[k], rw, rh, 4 * rw, frame_ptr[k], w, h, 4 * w, gazes[k][0], gazes[k][1]))}
+            if w % 4 == 0 and h % 2 == 0:
+                py = torch.randint(0, 256, (B, h, w), dtype=torch.uint8, device=dev)
+                pu = torch.randint(0, 256, (B, h // 2, w // 2), dtype=torch.uint8, device=dev)
+                pv = torch.randint(0, 256, (B, h // 2, w // 2), dtype=torch.uint8, device=dev)
+                variants["two_calls_yuv420p"] = run_variant(lambda k: (
+                    encs[0].EncodeFrameYUV420PGPU(sat_ptr[0], py[k].data_ptr(), pu[k].data_ptr(),
+                                                  pv[k].data_ptr(), w, w // 2, w // 2, w, h),
+                    decs[0].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[0], (w, h),
+                                               gazes[k][0], gazes[k][1])))
+                variants["fused_yuv420p"] = run_variant(lambda k: decs[0].FoveateFrameRectYUV420PGPU(
+                    red_ptr[k], rw, rh, 4 * rw, py[k].data_ptr(), pu[k].data_ptr(), pv[k].data_ptr(),
+                    w, w // 2, w // 2, w, h, gazes[k][0], gazes[k][1]))
+            line["variants_mpix_per_s"] = variants
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, h, rw, rh)
         print(json.dumps(line), flush=True)
