@@ -22,10 +22,34 @@ __device__ __forceinline__ float mixf(float a, float b, float t) {
   return a + (b - a) * t;
 }
 
-__device__ __forceinline__ void copy_rgb(uint8_t *o, const uint8_t *s) {
-  o[0] = s[0];
-  o[1] = s[1];
-  o[2] = s[2];
+// host side: may a launch use 4-byte accesses?
+inline bool word_pixels(const void *dst, int dst_linesize, int dst_w, const void *src,
+                        int src_linesize, int src_w) {
+  return dst_linesize / dst_w == 4 && src_linesize / src_w == 4 && dst_linesize % 4 == 0 &&
+         src_linesize % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+}
+
+// A thread of the two point samplers owns kPointRows vertically adjacent reduced pixels: their
+// table loads and then their texel loads go out together (one pixel per thread is two dependent
+// round trips in a very short wave).
+constexpr int kPointRows = 4;
+
+// Three bytes of a pixel; the fourth byte of the target is the caller's.  `words`: source and
+// target are 4-byte aligned 4-byte pixels -> one load and two stores instead of three and three.
+__device__ __forceinline__ uint32_t load_px(const uint8_t *s, bool words) {
+  if (words) return *reinterpret_cast<const uint32_t *>(s);
+  return (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+}
+__device__ __forceinline__ void store_px(uint8_t *o, uint32_t v, bool words) {
+  if (words) {
+    *reinterpret_cast<uint16_t *>(o) = (uint16_t)v;
+    o[2] = (uint8_t)(v >> 16);
+    return;
+  }
+  o[0] = (uint8_t)v;
+  o[1] = (uint8_t)(v >> 8);
+  o[2] = (uint8_t)(v >> 16);
 }
 
 // sample_rect_kernel, src/image_sampler_sample_rect_kernel.cl:1-46
@@ -33,19 +57,29 @@ __global__ __launch_bounds__(256) void is_sample_rect_kernel(
     uint8_t *__restrict__ dst, int out_w, int out_h, int out_linesize, int obpp,
     const uint8_t *__restrict__ src, int src_w, int src_h, int src_linesize,
     int sbpp, const int16_t *__restrict__ gx, const int16_t *__restrict__ gy,
-    float cxf, float cyf) {
+    float cxf, float cyf, bool words) {
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (i >= out_w || j >= out_h) return;
+  const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPointRows;
+  if (i >= out_w || j0 >= out_h) return;
   int xp = (int)(cxf + (float)gx[i]);  // float add, then truncation (:24-25)
-  const int yp = (int)(cyf + (float)gy[j]);
   if (xp >= src_w)
     xp -= src_w;
   else if (xp < 0)
     xp += src_w;
-  if (xp >= 0 && xp < src_w && yp >= 0 && yp < src_h)
-    copy_rgb(dst + (size_t)j * out_linesize + (size_t)i * obpp,
-             src + (size_t)yp * src_linesize + (size_t)xp * sbpp);
+  int yp[kPointRows];
+#pragma unroll
+  for (int k = 0; k < kPointRows; ++k)
+    yp[k] = (int)(cyf + (float)gy[min(j0 + k, out_h - 1)]);
+  const bool x_ok = xp >= 0 && xp < src_w;
+  uint32_t px[kPointRows];
+#pragma unroll
+  for (int k = 0; k < kPointRows; ++k)
+    if (x_ok && yp[k] >= 0 && yp[k] < src_h)
+      px[k] = load_px(src + (size_t)yp[k] * src_linesize + (size_t)xp * sbpp, words);
+#pragma unroll
+  for (int k = 0; k < kPointRows; ++k)
+    if (j0 + k < out_h && x_ok && yp[k] >= 0 && yp[k] < src_h)
+      store_px(dst + (size_t)(j0 + k) * out_linesize + (size_t)i * obpp, px[k], words);
 }
 
 // sample_logpolar_kernel, src/image_sampler_sample_logpolar_kernel.cl:41-86,
@@ -55,20 +89,34 @@ __global__ __launch_bounds__(256) void is_sample_logpolar_kernel(
     uint8_t *__restrict__ dst, int out_w, int out_h, int out_linesize, int obpp,
     const uint8_t *__restrict__ src, int src_w, int src_h, int src_linesize,
     int sbpp, const float *__restrict__ rad, const float *__restrict__ cs,
-    const float *__restrict__ sn, float cxf, float cyf) {
+    const float *__restrict__ sn, float cxf, float cyf, bool words) {
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (i >= out_w || j >= out_h) return;
+  const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPointRows;
+  if (i >= out_w || j0 >= out_h) return;
   const float r = rad[i];
-  const int gxv = (int)(int16_t)(int)(r * cs[j]);
-  const int gyv = (int)(int16_t)(int)(r * sn[j]);
-  int xp = (int)(cxf + (float)gxv);
-  int yp = (int)(cyf + (float)gyv);
-  xp = (xp + 10 * src_w) % src_w;
-  yp = min(max(yp, 0), src_h - 1);
-  if (xp >= 0 && xp < src_w && yp >= 0 && yp < src_h)
-    copy_rgb(dst + (size_t)j * out_linesize + (size_t)i * obpp,
-             src + (size_t)yp * src_linesize + (size_t)xp * sbpp);
+  float cj[kPointRows], sj[kPointRows];
+#pragma unroll
+  for (int k = 0; k < kPointRows; ++k) {
+    cj[k] = cs[min(j0 + k, out_h - 1)];
+    sj[k] = sn[min(j0 + k, out_h - 1)];
+  }
+  uint32_t px[kPointRows];
+  bool ok[kPointRows];
+#pragma unroll
+  for (int k = 0; k < kPointRows; ++k) {
+    const int gxv = (int)(int16_t)(int)(r * cj[k]);
+    const int gyv = (int)(int16_t)(int)(r * sj[k]);
+    int xp = (int)(cxf + (float)gxv);
+    int yp = (int)(cyf + (float)gyv);
+    xp = (xp + 10 * src_w) % src_w;
+    yp = min(max(yp, 0), src_h - 1);
+    ok[k] = xp >= 0 && xp < src_w && yp >= 0 && yp < src_h;
+    if (ok[k]) px[k] = load_px(src + (size_t)yp * src_linesize + (size_t)xp * sbpp, words);
+  }
+#pragma unroll
+  for (int k = 0; k < kPointRows; ++k)
+    if (j0 + k < out_h && ok[k])
+      store_px(dst + (size_t)(j0 + k) * out_linesize + (size_t)i * obpp, px[k], words);
 }
 
 // interpolate_logpolar_kernel, src/image_sampler_interpolate_kernel.cl:1-81
@@ -405,14 +453,16 @@ int f360_is_sample_rect(f360_image_sampler *is, uint8_t *target_dev,
                "f360_is_sample_rect: need >= 3 bytes per pixel");
   F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),
                "f360_is_sample_rect: gaze centre out of range");
-  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  const dim3 grid((target_width + 63) / 64, (target_height + 4 * kPointRows - 1) / (4 * kPointRows));
   hipLaunchKernelGGL(is_sample_rect_kernel, grid, dim3(256), 0, is->ctx->stream,
                      target_dev, target_width, target_height, target_linesize,
                      target_linesize / target_width, source_dev, source_width,
                      source_height, source_linesize, source_linesize / source_width,
                      is->gx_dev.as<int16_t>(), is->gy_dev.as<int16_t>(),
                      center_x * (float)source_width,
-                     center_y * (float)source_height);
+                     center_y * (float)source_height,
+                     word_pixels(target_dev, target_linesize, target_width, source_dev,
+                                 source_linesize, source_width));
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }
@@ -438,14 +488,16 @@ int f360_is_sample_logpolar(f360_image_sampler *is, uint8_t *target_dev,
                "f360_is_sample_logpolar: need >= 3 bytes per pixel");
   F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),
                "f360_is_sample_logpolar: gaze centre out of range");
-  const dim3 grid((target_width + 63) / 64, (target_height + 3) / 4);
+  const dim3 grid((target_width + 63) / 64, (target_height + 4 * kPointRows - 1) / (4 * kPointRows));
   hipLaunchKernelGGL(is_sample_logpolar_kernel, grid, dim3(256), 0, is->ctx->stream,
                      target_dev, target_width, target_height, target_linesize,
                      target_linesize / target_width, source_dev, source_width,
                      source_height, source_linesize, source_linesize / source_width,
                      is->lrad_dev.as<float>(), is->lcos_dev.as<float>(),
                      is->lsin_dev.as<float>(), center_x * (float)source_width,
-                     center_y * (float)source_height);
+                     center_y * (float)source_height,
+                     word_pixels(target_dev, target_linesize, target_width, source_dev,
+                                 source_linesize, source_width));
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }
