@@ -54,7 +54,7 @@ static uint64_t fnv1a64(const void *p, size_t n) {
 }
 
 static void client_loop(int client, int device, double fps, int frames, int width, int height,
-                        const GazeViewPoints *trace, ClientResult *out) {
+                        const GazeViewPoints *trace, bool planar, ClientResult *out) {
   using clock = std::chrono::high_resolution_clock;
   // ---- InitializeConnectionData (video_server.cc:62-66) --------------------------------
   OpenCLManager cl_manager;
@@ -68,7 +68,10 @@ static void client_loop(int client, int device, double fps, int frames, int widt
 
   // ---- SendFrameLoop buffers (video_server.cc:224-232) -----------------------------------
   const int linesize = 4 * width, out_linesize = 4 * out_w;
-  const size_t cl_source_frame_size = (size_t)linesize * height;
+  // planar: the decoder's yuv420p frame (Y, U, V back to back, tight rows) is uploaded as it is --
+  // 1.5 instead of 4 bytes per pixel over PCIe -- and converted inside the encode kernels
+  const size_t y_bytes = (size_t)width * height, c_bytes = y_bytes / 4;
+  const size_t cl_source_frame_size = planar ? y_bytes + 2 * c_bytes : (size_t)linesize * height;
   cl::Buffer cl_source_frame(cl_manager.context, CL_MEM_READ_WRITE, cl_source_frame_size);
   cl::Buffer cl_sat_buffer(cl_manager.context, CL_MEM_READ_WRITE,
                            (size_t)3 * width * height * sizeof(uint32_t));
@@ -99,7 +102,14 @@ static void client_loop(int client, int device, double fps, int frames, int widt
     const auto t0 = clock::now();
     uint8_t *rgb = staged[frame_number % pool];  // video_decoder->GetFrame(rgb_frame, RGB0)
     cl_int ret = cl::copy(cl_manager.command_queue, rgb, rgb + cl_source_frame_size, cl_source_frame);
-    sat_encoder.EncodeFrameGPU(cl_sat_buffer(), cl_source_frame(), width, height, linesize);
+    if (planar) {
+      uint8_t *base = static_cast<uint8_t *>(cl_source_frame());
+      sat_encoder.EncodeFrameYUV420PGPU(cl_sat_buffer(), base, base + y_bytes,
+                                        base + y_bytes + c_bytes, width, width / 2, width / 2,
+                                        width, height);
+    } else {
+      sat_encoder.EncodeFrameGPU(cl_sat_buffer(), cl_source_frame(), width, height, linesize);
+    }
     clFlush(cl_manager.command_queue());
     clFinish(cl_manager.command_queue());
     const auto t1 = clock::now();
@@ -148,6 +158,7 @@ int main(int argc, char **argv) {
   const int height = argc > 5 ? atoi(argv[5]) : 3840;
   const std::string trace_path = argc > 6 ? argv[6] : "";
   int gpus = argc > 7 ? atoi(argv[7]) : 0;
+  const bool planar = argc > 8 && std::string(argv[8]) == "yuv420p";
   if (gpus <= 0 && f360_device_count(&gpus) != F360_OK) {
     std::cerr << f360_last_error_string() << std::endl;
     return EXIT_FAILURE;
@@ -160,7 +171,7 @@ int main(int argc, char **argv) {
   const auto t0 = std::chrono::high_resolution_clock::now();
   for (int c = 0; c < clients; ++c)
     threads.emplace_back(client_loop, c, c % gpus, fps, frames, width, height,
-                         trace.points.empty() ? nullptr : &trace, &results[(size_t)c]);
+                         trace.points.empty() ? nullptr : &trace, planar, &results[(size_t)c]);
   for (auto &t : threads) t.join();
   const double wall_s =
       std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -177,11 +188,12 @@ int main(int argc, char **argv) {
   }
   std::sort(all.begin(), all.end());
   auto pct = [&](double q) { return all.empty() ? 0.0 : all[(size_t)std::min<double>(all.size() - 1, q * all.size())]; };
-  printf("{\"clients\": %d, \"gpus\": %d, \"fps_target\": %.1f, \"frames_per_client\": %d, \"width\": %d, "
+  printf("{\"source\": \"%s\", \"clients\": %d, \"gpus\": %d, \"fps_target\": %.1f, \"frames_per_client\": %d, \"width\": %d, "
          "\"height\": %d, \"wall_s_with_setup\": %.3f, \"fps_achieved_per_client\": %.2f, \"mpix_per_s\": %.1f, "
          "\"latency_ms_p50\": %.3f, \"latency_ms_p99\": %.3f, \"latency_ms_max\": %.3f, "
          "\"client0_last_gaze\": [%.9g, %.9g], \"client0_last_digest\": \"%016llx\"}\n",
-         clients, gpus, fps, frames, width, height, wall_s, fps_sum / clients,
+         planar ? "yuv420p" : "rgb0", clients, gpus, fps, frames, width, height, wall_s,
+         fps_sum / clients,
          loop_max > 0 ? (double)total_frames * width * height / 1e6 / loop_max : 0.0, pct(0.50), pct(0.99),
          all.empty() ? 0.0 : all.back(), results[0].last_gaze[0], results[0].last_gaze[1],
          (unsigned long long)results[0].last_digest);

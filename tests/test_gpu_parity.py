@@ -537,6 +537,24 @@ def test_send_frame_loop_example(f360, gpu_ctx, oracle, tmp_path):
     oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, oracle.satdec_grid(rw, rh, w, h),
                               float(cx), float(cy))
     assert res["client0_last_digest"] != "0" * 16
+    # the same loop fed with planar frames (uploaded as they are, converted in the encoder)
+    out = subprocess.run([os.path.join(repo, "examples", "send_frame_loop_synth"), "1", "120",
+                          str(frames), str(w), str(h), str(trace), "1", "yuv420p"],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["source"] == "yuv420p"
+    buf = oracle.lcg_frame(w, h, 12345 + (k % 3)).reshape(-1)
+    y = buf[:w * h].reshape(h, w)
+    u = buf[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)
+    v = buf[w * h + w * h // 4:w * h + w * h // 2].reshape(h // 2, w // 2)
+    sat = oracle.sat_encode(oracle.yuv420p_to_rgb0(y, u, v, w, h, oracle.YUV_SWS_X86), w, h, 4 * w)
+    red = np.zeros((rh, 4 * rw), dtype=np.uint8)
+    oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, oracle.satdec_grid(rw, rh, w, h),
+                              float(cx), float(cy))
+    # a single client at one fixed trace: every tick writes the pixels its gaze covers; with the
+    # Lissajous trace earlier gazes leave pixels behind, so only existence of output is asserted
+    assert res["client0_last_digest"] != "0" * 16
 
 
 # --------------------------------------------------------------------- odd geometries / threads
