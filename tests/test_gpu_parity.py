@@ -927,3 +927,30 @@ def test_gnomonic_table_equals_direct_evaluation(f360, gpu_ctx, oracle):
         gpu_ctx.set_option("gnomonic.table", 1)
     for buf in (src, a, b):
         buf.free()
+
+
+def test_fused_foveation_long_axes(f360, gpu_ctx, oracle):
+    """Fused path with an axis longer than the lattice maps keep in LDS (8192 entries) and more
+    reduced columns than a thread keeps in registers (5120): the in-place / looped fallbacks."""
+    w, h, rw, rh = 8704, 16, 6000, 12
+    frame = oracle.lcg_frame(w, h, 321)
+    sat_h = oracle.sat_encode(frame, w, h, 4 * w)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    dec = f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    src = gpu_ctx.upload(frame)
+    dst = gpu_ctx.malloc(rh * 4 * rw)
+    try:
+        for piggyback in (1, 0):
+            gpu_ctx.set_option("fov.piggyback", piggyback)
+            for (cx, cy) in [(0.5, 0.5), (0.02, 0.9), (0.999, 0.1)]:
+                want = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+                oracle.satdec_sample_rect(want, rw, rh, 4 * rw, sat_h, w, h, grid, cx, cy)
+                dst.fill(0xA5)
+                dec.FoveateFrameRectGPU(dst.ptr, rw, rh, 4 * rw, src.ptr, w, h, 4 * w, cx, cy)
+                assert np.array_equal(dst.copy_to_host(np.uint8, (rh, 4 * rw)), want), (piggyback, cx, cy)
+    finally:
+        gpu_ctx.set_option("fov.piggyback", 1)
+    src.free()
+    dst.free()
+    dec.close()
