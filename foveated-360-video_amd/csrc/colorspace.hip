@@ -38,10 +38,19 @@ __global__ __launch_bounds__(256) void yuv420p_to_rgb0_kernel(uint8_t *__restric
   f360::yuv_pixels4<MODEL>(k, ya, uv, a);
   f360::yuv_pixels4<MODEL>(k, yb, uv, b);
   const uint32_t alpha = 0xff000000u;  // yuv2rgb.c:983-984 / SET_EMPTY_ALPHA
+#ifdef F360_NO_NT_STORES
   *reinterpret_cast<u32x4_c *>(dst + (size_t)y0 * dst_linesize + (size_t)x0 * 4) =
       u32x4_c{a[0] | alpha, a[1] | alpha, a[2] | alpha, a[3] | alpha};
   *reinterpret_cast<u32x4_c *>(dst + (size_t)(y0 + 1) * dst_linesize + (size_t)x0 * 4) =
       u32x4_c{b[0] | alpha, b[1] | alpha, b[2] | alpha, b[3] | alpha};
+#else  // streaming output: non-temporal, see sat_encode.hip
+  __builtin_nontemporal_store(
+      (u32x4_c{a[0] | alpha, a[1] | alpha, a[2] | alpha, a[3] | alpha}),
+      reinterpret_cast<u32x4_c *>(dst + (size_t)y0 * dst_linesize + (size_t)x0 * 4));
+  __builtin_nontemporal_store(
+      (u32x4_c{b[0] | alpha, b[1] | alpha, b[2] | alpha, b[3] | alpha}),
+      reinterpret_cast<u32x4_c *>(dst + (size_t)(y0 + 1) * dst_linesize + (size_t)x0 * 4));
+#endif
 }
 
 // Any width, any alignment: one pixel per thread, byte loads.

@@ -20,6 +20,14 @@
 
 namespace {
 
+// Streaming outputs (written once, consumed later by another kernel or a copy engine) are stored
+// non-temporally: see global_store_b128_uncounted_nt in sat_encode.hip.
+#ifdef F360_NO_NT_STORES
+#define F360_STREAM_STORE(ptr, value) (*(ptr) = (value))
+#else
+#define F360_STREAM_STORE(ptr, value) __builtin_nontemporal_store((value), (ptr))
+#endif
+
 using f360::AxisBox;
 using f360::FovMaps;
 using f360::sample_axis;  // one axis of sample_rect_kernel's box rule (fov_maps.h)
@@ -130,9 +138,12 @@ struct SampleArgs {
                                // most recently written, hence the likeliest to be cached)
 };
 
+// Non-temporal: the reduced frame is read next by a copy engine or another kernel, and dirty lines
+// left in L2 / Infinity Cache are written back at the expense of the next frame's reducer.
 __device__ __forceinline__ void store_rgb(uint8_t *o, uint32_t r, uint32_t g, uint32_t b) {
-  *reinterpret_cast<uint16_t *>(o) = (uint16_t)((r & 0xffu) | ((g & 0xffu) << 8));
-  o[2] = (uint8_t)b;
+  __builtin_nontemporal_store((uint16_t)((r & 0xffu) | ((g & 0xffu) << 8)),
+                              reinterpret_cast<uint16_t *>(o));
+  __builtin_nontemporal_store((uint8_t)b, o + 2);
 }
 
 // One wave: reduced columns [c0, c0 + 63) clipped to [col_begin, col_end), rows [j0, j1).
@@ -696,8 +707,9 @@ __global__ __launch_bounds__(256) void decode_strip_kernel(
         px[k] = (keep & 0xff000000u) | v[0] | (v[1] << 8) | (v[2] << 16);
       }
       if (writes)
-        *reinterpret_cast<u32x4_d *>(dst + (size_t)(yb + r) * dst_linesize + (size_t)x0 * 4) =
-            u32x4_d{px[0], px[1], px[2], px[3]};
+        F360_STREAM_STORE(
+            reinterpret_cast<u32x4_d *>(dst + (size_t)(yb + r) * dst_linesize + (size_t)x0 * 4),
+            (u32x4_d{px[0], px[1], px[2], px[3]}));
       up = c;
     }
   }
@@ -856,7 +868,7 @@ __global__ __launch_bounds__(256) void interpolate_rect_kernel(
     }
     uint32_t *o = dst + (size_t)y * out_w + x_base;
     if (vec_store && x_base < out_w) {
-      *reinterpret_cast<uint4 *>(o) = make_uint4(out[0], out[1], out[2], out[3]);
+      F360_STREAM_STORE(reinterpret_cast<u32x4_t *>(o), (u32x4_t{out[0], out[1], out[2], out[3]}));
     } else {
 #pragma unroll
       for (int k = 0; k < kInterpCols; ++k)
