@@ -94,7 +94,7 @@ struct f360_ctx {
   f360::SatEncodePlan enc;
   // options (f360_ctx_set_option)
   int opt_band_rows = 0;       // "sat.band_rows": 0 (by frame size) | 16 | 32 | 64
-  int opt_sb_bands = -1;       // "sat.sb_bands": bands per reducer wave (-1: 2, planar sources 1; 0: as few super-bands as 32)
+  int opt_sb_bands = -1;       // "sat.sb_bands": bands per reducer wave (-1: 1 for planar sources and 64-row bands, else 2; 0: as few super-bands as 32)
   int opt_store_mode = 1;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-staged contiguous stores
   int opt_sample_variant = 1;  // "sample.variant": 0 per-pixel, 1 column walker, 2 row streaming, 3 hybrid
   int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker

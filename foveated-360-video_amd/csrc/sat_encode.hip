@@ -448,7 +448,8 @@ __device__ __forceinline__ void carry_scan_segment(const ScanSeg &s, int blk) {
   const int i = blk * 256 + (int)threadIdx.x;
   if (i >= s.n) return;
   uint32_t run = 0;
-  for (int k = 0; k < s.K; k += 32) {  // 32 loads in flight per lane
+  for (int k = 0; k < s.K; k += 32) {  // 32 loads in flight per lane (64 measured slower, also
+                                       // for the 60 super-bands of an 8K frame: 11.4 vs 8.8 us)
     uint32_t t[32];
 #pragma unroll
     for (int q = 0; q < 32; ++q)
@@ -690,7 +691,10 @@ int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false) {
   // (planar sources convert in the reducer, which makes it instruction-bound: one band per
   // wave doubles the waves, 45 -> 34 us at 8K)
   int sb_bands = ctx->opt_sb_bands;
-  if (sb_bands < 0) sb_bands = planar ? 1 : 2;
+  // (with 64-row bands one band per reducer wave also makes the reducer visit the frame in the
+  // writer's tile order, and the writer's re-read then finds more of it in the caches: 80 -> 76 us
+  // at 8K for +1.7 us in the carry kernel; with 16-row bands two bands per wave stay better)
+  if (sb_bands < 0) sb_bands = (planar || band_rows == 64) ? 1 : 2;
   if (sb_bands == 0) {
     const int nb = (height + band_rows - 1) / band_rows;
     sb_bands = (nb + 31) / 32;
