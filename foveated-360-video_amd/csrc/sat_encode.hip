@@ -418,7 +418,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_reduce_kernel(
       if (t < nbatch) {
         const int band = band0 + t / bpb;
         const int in_band = t % bpb;
-        if (in_band == 0) store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, st.col);
+        if (in_band == 0 && a.sb_bands != 1)
+          store12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, st.col);
         reduce_rows<SRC>(a, st, buf[d], y_first + t * kRowUnroll, y_stop,
                          in_band * kRowUnroll, rows_lds, lane);
         if (in_band == bpb - 1) {
@@ -517,10 +518,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   uint32_t acc[12];
   {
     uint32_t t0[12], t1[12];
-    load12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, t0);
     load12(a.sbprefix + (size_t)sb * a.wp3 + (size_t)x0 * 3, t1);
+    if (a.sb_bands == 1) {  // a band is its own super-band: nothing above it inside
 #pragma unroll
-    for (int e = 0; e < 12; ++e) acc[e] = t0[e] + t1[e];
+      for (int e = 0; e < 12; ++e) acc[e] = t1[e];
+    } else {
+      load12(a.lp + (size_t)band * a.wp3 + (size_t)x0 * 3, t0);
+#pragma unroll
+      for (int e = 0; e < 12; ++e) acc[e] = t0[e] + t1[e];
+    }
   }
   // corner: every tile above and to the left
   uint32_t corner[3] = {0, 0, 0};
