@@ -448,39 +448,71 @@ struct ScanSeg {
   int n, K, nblocks;
 };
 
-__device__ __forceinline__ void carry_scan_segment(const ScanSeg &s, int blk) {
-  const int i = blk * 256 + (int)threadIdx.x;
-  if (i >= s.n) return;
-  uint32_t run = 0;
-  for (int k = 0; k < s.K; k += 32) {  // 32 loads in flight per lane (64 measured slower, also
-                                       // for the 60 super-bands of an 8K frame: 11.4 vs 8.8 us)
-    uint32_t t[32];
+// One round of at most 32 loads per thread: a segment with more than 32 rows is split into
+// `parts` row ranges handled by different threads of the workgroup (the workgroup then covers
+// 256 / parts columns); a part's base is the sum of the parts before it, passed through LDS.
+// (Two rounds in one thread: 8.8 us for the 60 super-bands of an 8K frame; 64 loads in flight: 11.4.)
+__device__ __forceinline__ void carry_scan_segment(const ScanSeg &s, int blk, uint32_t *totals) {
+  if (s.K > 128) {  // very tall / wide frames: rounds of 32 in one thread
+    const int i = blk * 256 + (int)threadIdx.x;
+    if (i >= s.n) return;
+    uint32_t run = 0;
+    for (int k = 0; k < s.K; k += 32) {
+      uint32_t t[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q)
-      t[q] = (k + q < s.K) ? s.in[(size_t)(k + q) * s.n + i] : 0u;
+      for (int q = 0; q < 32; ++q) t[q] = (k + q < s.K) ? s.in[(size_t)(k + q) * s.n + i] : 0u;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-      if (k + q < s.K) s.out[(size_t)(k + q) * s.n + i] = run;
-      run += t[q];
+      for (int q = 0; q < 32; ++q) {
+        if (k + q < s.K) s.out[(size_t)(k + q) * s.n + i] = run;
+        run += t[q];
+      }
     }
+    return;
+  }
+  const int parts = (s.K + 31) / 32;           // 1, 2 (8K), 3 or 4
+  const int cols = 256 / parts;                // columns per workgroup
+  const int part = (int)threadIdx.x / cols, c = (int)threadIdx.x - part * cols;
+  const int i = blk * cols + c;
+  const int rows = (s.K + parts - 1) / parts;  // rows per part, <= 32
+  const int k0 = part * rows, k1 = min(k0 + rows, s.K);
+  const bool live = part < parts && i < s.n;
+  uint32_t t[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) t[q] = (live && k0 + q < k1) ? s.in[(size_t)(k0 + q) * s.n + i] : 0u;
+  uint32_t base = 0;
+  if (parts > 1) {  // wave-uniform
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) sum += t[q];
+    totals[threadIdx.x] = sum;
+    __syncthreads();
+    for (int p = 0; p < part; ++p) base += totals[p * cols + c];
+  }
+  if (!live) return;
+  uint32_t run = base;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    if (k0 + q < k1) s.out[(size_t)(k0 + q) * s.n + i] = run;
+    run += t[q];
   }
 }
 
 __global__ __launch_bounds__(256) void sat_carry_kernel(const ScanSeg a,
                                                         const ScanSeg b,
                                                         const ScanSeg c) {
+  __shared__ uint32_t totals[256];
   int blk = blockIdx.x;
   if (blk < a.nblocks) {
-    carry_scan_segment(a, blk);
+    carry_scan_segment(a, blk, totals);
     return;
   }
   blk -= a.nblocks;
   if (blk < b.nblocks) {
-    carry_scan_segment(b, blk);
+    carry_scan_segment(b, blk, totals);
     return;
   }
   blk -= b.nblocks;
-  carry_scan_segment(c, blk);
+  carry_scan_segment(c, blk, totals);
 }
 
 // ---- K3: final table ----------------------------------------------------------
@@ -847,10 +879,13 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   }
 
   if (ctx->opt_ablate & 8) return F360_OK;  // timing experiments: reducer only
-  ScanSeg sa{p.sbtotal, p.sbprefix, p.wp3, p.nsb, (p.wp3 + 255) / 256};
-  ScanSeg sb{p.rowsum, p.rowcarry, height * 3, p.nstrips, (height * 3 + 255) / 256};
-  ScanSeg sc{p.tiletotal, p.tprefix, p.nbands * 3, p.nstrips,
-             (p.nbands * 3 + 255) / 256};
+  auto seg = [](const uint32_t *in, uint32_t *out, int n, int K) {
+    const int parts = K > 128 ? 1 : (K + 31) / 32, cols = 256 / (parts < 1 ? 1 : parts);
+    return ScanSeg{in, out, n, K, (n + cols - 1) / cols};
+  };
+  ScanSeg sa = seg(p.sbtotal, p.sbprefix, p.wp3, p.nsb);
+  ScanSeg sb = seg(p.rowsum, p.rowcarry, height * 3, p.nstrips);
+  ScanSeg sc = seg(p.tiletotal, p.tprefix, p.nbands * 3, p.nstrips);
   {
     f360::KernelSpan span(ctx, f360::kSatCarry, prof);
     hipLaunchKernelGGL(sat_carry_kernel,

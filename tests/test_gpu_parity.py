@@ -954,3 +954,23 @@ def test_fused_foveation_long_axes(f360, gpu_ctx, oracle):
     src.free()
     dst.free()
     dec.close()
+
+
+@pytest.mark.parametrize("w,h,band_rows,sb_bands", [(260, 2100, 16, 1),    # 132 super-bands: carry fallback
+                                                    (260, 1100, 16, 1),    # 69: three row ranges per column
+                                                    (8448, 40, 16, 2),     # 33 strips: two ranges
+                                                    (34000, 8, 16, 2)])    # 133 strips: fallback
+def test_sat_encode_long_carry_scans(f360, gpu_ctx, oracle, w, h, band_rows, sb_bands):
+    """The carry kernel splits scans longer than 32 rows across threads (up to 128 rows) and
+    falls back to rounds in one thread beyond that."""
+    frame = oracle.lcg_frame(w, h, 78)
+    want = oracle.sat_encode(frame, w, h, 4 * w)
+    old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands")}
+    try:
+        gpu_ctx.set_option("sat.band_rows", band_rows)
+        gpu_ctx.set_option("sat.sb_bands", sb_bands)
+        got = gpu_sat(f360, gpu_ctx, frame, w, h, 4 * w)
+    finally:
+        for k, v in old.items():
+            gpu_ctx.set_option(k, v)
+    assert np.array_equal(got, want)
