@@ -191,11 +191,15 @@ int main(int argc, char **argv) {
   printf("{\"source\": \"%s\", \"clients\": %d, \"gpus\": %d, \"fps_target\": %.1f, \"frames_per_client\": %d, \"width\": %d, "
          "\"height\": %d, \"wall_s_with_setup\": %.3f, \"fps_achieved_per_client\": %.2f, \"mpix_per_s\": %.1f, "
          "\"latency_ms_p50\": %.3f, \"latency_ms_p99\": %.3f, \"latency_ms_max\": %.3f, "
-         "\"client0_last_gaze\": [%.9g, %.9g], \"client0_last_digest\": \"%016llx\"}\n",
+         "\"client0_last_gaze\": [%.9g, %.9g], \"client0_last_digest\": \"%016llx\", \"last_digests\": [",
          planar ? "yuv420p" : "rgb0", clients, gpus, fps, frames, width, height, wall_s,
          fps_sum / clients,
          loop_max > 0 ? (double)total_frames * width * height / 1e6 / loop_max : 0.0, pct(0.50), pct(0.99),
          all.empty() ? 0.0 : all.back(), results[0].last_gaze[0], results[0].last_gaze[1],
          (unsigned long long)results[0].last_digest);
+  // every client's delivered bytes (digest of its last output buffer), for the parity test
+  for (size_t c = 0; c < results.size(); ++c)
+    printf("%s\"%016llx\"", c ? ", " : "", (unsigned long long)results[c].last_digest);
+  printf("]}\n");
   return EXIT_SUCCESS;
 }

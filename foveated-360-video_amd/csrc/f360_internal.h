@@ -98,6 +98,10 @@ struct f360_ctx {
   int opt_store_mode = 1;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-staged contiguous stores
   int opt_sample_variant = 1;  // "sample.variant": 0 per-pixel, 1 column walker, 2 row streaming, 3 hybrid
   int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker
+  int opt_stream_rows = 32;    // "sample.srows": reduced rows per wave of the row streamer (variant 4), <= 64
+  int opt_stream_spread = 1;   // "sample.spread": consecutive streamer waves take items a quarter block apart (heavy / light mix per CU)
+  int opt_stream_hsplit = 1;   // "sample.hsplit": a heavy (fovea) tile's rows are split over this many waves (1 | 2 | 4)
+  int opt_stream_depth = 4;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 4 | 6)
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
@@ -188,6 +192,7 @@ struct f360_sat_decoder {
   f360::DevBuf gx_dev, gy_dev;
   // row-streaming sampler: inverse of the x grid, largest corner step (+1, rounded to 4)
   f360::DevBuf lbx_dev;
+  std::vector<int> lbx_host;
   int lb_dmin = 0, lb_n = 0, halo = 0;
   bool stream_ok = false;
   int dense_begin = 0, dense_end = 0;  // reduced columns with unit corner steps (fovea)

@@ -11,6 +11,7 @@
 // 1-D tables built on the host (host_tables.cpp) so the kernels below are pure
 // integer / IEEE-float gather kernels.
 #include <algorithm>
+#include <numeric>
 #include <cmath>
 #include <cstring>
 
@@ -476,6 +477,8 @@ __global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArg
   if (tile >= (a.src_w + kTileTexels - 1) / kTileTexels) return;
   stream_body<PASSES>(a, tile, j0, (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]));
 }
+
+#include "sample_stream.h"
 
 // ---------------------------------------------------------------------------
 // Fused foveation (SURVEY.md 8f-1 i): frame -> reduced frame without materialising the table.
@@ -1021,6 +1024,7 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
     }
     st = upload(dec->ctx, dec->lbx_dev, lb.data(), lb.size() * sizeof(int));
     if (st != F360_OK) return st;
+    dec->lbx_host = std::move(lb);
   }
   dec->gw = target_width;
   dec->gh = target_height;
@@ -1097,14 +1101,73 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   sa.ablate = ctx->opt_ablate;
   sa.reverse = ctx->opt_sample_reverse;
   const int variant = ctx->opt_sample_variant;
+  // the streaming variants' per-geometry tables (inverse grid, halo, candidate bounds) belong to
+  // the source size the grid was initialised for; any other size takes the walker
   const bool can_stream = dec->stream_ok && (source_width % 4) == 0 &&
+                          source_width == dec->sw && source_height == dec->sh &&
                           (size_t)source_width * source_height * 12 < ((size_t)1 << 32) &&
                           ((uintptr_t)sat_dev % 16) == 0 && source_height <= 0xffff &&
                           target_height < 0xffff;
   const int tile_blocks = ((source_width + kTileTexels - 1) / kTileTexels + 3) / 4;
   const int run_blocks = (target_height + kStreamRows - 1) / kStreamRows;
   f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
-  if (variant == 3 && can_stream && dec->hybrid_passes > 0) {
+  int s4_passes = 0, s4_rot = 0, s4_th = 0;
+  if (variant == 4 && can_stream && dec->halo <= kS4MaxHalo) {
+    // candidates per tile for THIS gaze (the kernel enumerates exactly these windows)
+    const int ntiles = (source_width + kS4Tile - 1) / kS4Tile;
+    const std::vector<int> &lb = dec->lbx_host;
+    auto lb_at = [&](long d) {
+      return lb[(size_t)std::min<long>(std::max<long>(d - dec->lb_dmin, 0), (long)lb.size() - 1)];
+    };
+    int worst = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      int total = 0;
+      for (int k = -1; k <= 1; ++k) {
+        const long lo_b = (long)t * kS4Tile + (long)k * source_width - cxp;
+        const long hi_b = lo_b + kS4Tile + (t == ntiles - 1 ? dec->halo : 0);
+        const int i_lo = std::max(lb_at(lo_b) - 1, 0);
+        const int i_hi = std::max(std::min(lb_at(hi_b) - 1, target_width), i_lo);
+        total += i_hi - i_lo;
+      }
+      worst = std::max(worst, total);
+    }
+    s4_passes = worst <= 64 * 4 ? 4 : (worst <= 64 * 6 ? 6 : 0);
+    // heavy tiles: those that overlap the fovea's unit-step columns (right corners
+    // cxp + gx[dense_begin + 1] .. cxp + gx[dense_end])
+    if (dec->dense_end > dec->dense_begin) {
+      auto floordiv = [](long v, long d) { return v >= 0 ? v / d : -((-v + d - 1) / d); };
+      const long t0 = floordiv((long)cxp + dec->gx_host[(size_t)dec->dense_begin + 1], kS4Tile);
+      const long t1 = floordiv((long)cxp + dec->gx_host[(size_t)dec->dense_end], kS4Tile);
+      s4_th = (int)std::min<long>(t1 - t0 + 1, ntiles);
+      s4_rot = (int)(((t0 % ntiles) + ntiles) % ntiles);
+    }
+  }
+  if (s4_passes > 0) {
+    const int hsplit = ctx->opt_stream_hsplit;
+    int rows = std::min(ctx->opt_stream_rows, kS4MaxRows);
+    rows = std::max(rows / hsplit, 1) * hsplit;
+    const int nblocks = (target_height + rows - 1) / rows;
+    const int ntiles = (source_width + kS4Tile - 1) / kS4Tile;
+    const int per_block = hsplit * s4_th + (ntiles - s4_th);
+    const int items = per_block * nblocks;
+    int istride = ctx->opt_stream_spread ? std::max(per_block / 4, 1) : 1;
+    while (std::gcd(istride, per_block) != 1) ++istride;
+    const dim3 sgrid((unsigned)((items + 3) / 4));
+    const int depth = ctx->opt_stream_depth;
+#define F360_S4_LAUNCH(P, D)                                                              \
+  hipLaunchKernelGGL((sample_rect_stream4_kernel<P, D>), sgrid, dim3(256), 0, ctx->stream, sa, \
+                     rows, nblocks, hsplit, s4_th, s4_rot, istride)
+    if (s4_passes == 4) {
+      if (depth == 2) F360_S4_LAUNCH(4, 2);
+      else if (depth == 4) F360_S4_LAUNCH(4, 4);
+      else F360_S4_LAUNCH(4, 6);
+    } else {
+      if (depth == 2) F360_S4_LAUNCH(6, 2);
+      else if (depth == 4) F360_S4_LAUNCH(6, 4);
+      else F360_S4_LAUNCH(6, 6);
+    }
+#undef F360_S4_LAUNCH
+  } else if (variant == 3 && can_stream && dec->hybrid_passes > 0) {
     sa.dense_begin = dec->dense_begin;
     sa.dense_end = dec->dense_end;
     sa.walk_blocks =

@@ -88,8 +88,20 @@ def main():
             red = np.full((rh, rw * 4), 0xA5, dtype=np.uint8)
             ob.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, grid, cx, cy)
             ent[f"sample_rect_{k}"] = f"{ob.fnv1a64(red):016x}"
-            if w <= 3840:
-                ent[f"interp_rect_{k}"] = f"{ob.fnv1a64(ob.satdec_interpolate_rect(red, w, h, rw, rh, cx, cy)):016x}"
+            ent[f"interp_rect_{k}"] = f"{ob.fnv1a64(ob.satdec_interpolate_rect(red, w, h, rw, rh, cx, cy)):016x}"
+        if w == 7680:
+            # planar source (the first 1.5*w*h bytes of the LCG stream as Y, U, V planes with
+            # tight rows) through the x86 libswscale model, then encode + sample
+            buf = frame.reshape(-1)
+            y = buf[:w * h].reshape(h, w)
+            u = buf[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)
+            v = buf[w * h + w * h // 4:w * h + w * h // 2].reshape(h // 2, w // 2)
+            ysat = ob.sat_encode(ob.yuv420p_to_rgb0(y, u, v, w, h, ob.YUV_SWS_X86), w, h, 4 * w)
+            ent["yuv_x86_sat"] = f"{ob.fnv1a64(ysat):016x}"
+            for k, (cx, cy) in enumerate(GAZES[:3]):
+                red = np.full((rh, rw * 4), 0xA5, dtype=np.uint8)
+                ob.satdec_sample_rect(red, rw, rh, 4 * rw, ysat, w, h, grid, cx, cy)
+                ent[f"yuv_x86_sample_rect_{k}"] = f"{ob.fnv1a64(red):016x}"
         # all-255 frame: the 8K table wraps mod 2^32 (255*7680*3840 > 2^32)
         white = np.full((h, 4 * w), 255, dtype=np.uint8)
         ent["sat_white"] = f"{ob.fnv1a64(ob.sat_encode(white, w, h, 4 * w)):016x}"

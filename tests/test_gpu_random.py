@@ -9,6 +9,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+SAMPLER_VARIANTS = (0, 1, 2, 3, 4)
+DEFAULT_SAMPLER = 4
+
+
 def reduced(n):
     return 16 * math.ceil(n / 1.8 / 16)
 
@@ -86,13 +90,13 @@ def test_random_sample_interpolate_fused(f360, gpu_ctx, oracle):
             cx, cy = random_gaze(rng)
             want = np.full((rh, ls), 0xA5, dtype=np.uint8)
             oracle.satdec_sample_rect(want, rw, rh, ls, sat_h, w, h, grid, cx, cy)
-            for variant in (0, 1, 2, 3):
+            for variant in SAMPLER_VARIANTS:
                 gpu_ctx.set_option("sample.variant", variant)
                 dst.fill(0xA5)
                 dec.SampleFrameRectGPU(dst.ptr, rw, rh, ls, sat.ptr, (w, h), cx, cy)
                 assert np.array_equal(dst.copy_to_host(np.uint8, (rh, ls)), want), \
                     (case, variant, w, h, rw, rh, cx, cy)
-            gpu_ctx.set_option("sample.variant", 1)
+            gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
             dst.fill(0xA5)
             dec.FoveateFrameRectGPU(dst.ptr, rw, rh, ls, src.ptr, w, h, 4 * w, cx, cy)
             assert np.array_equal(dst.copy_to_host(np.uint8, (rh, ls)), want), (case, "fused", w, h, rw, rh)
