@@ -96,12 +96,12 @@ struct f360_ctx {
   int opt_band_rows = 0;       // "sat.band_rows": 0 (by frame size) | 16 | 32 | 64
   int opt_sb_bands = -1;       // "sat.sb_bands": bands per reducer wave (-1: 1 for planar sources and 64-row bands, else 2; 0: as few super-bands as 32)
   int opt_store_mode = 1;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-staged contiguous stores
-  int opt_sample_variant = 1;  // "sample.variant": 0 per-pixel, 1 column walker, 2 row streaming, 3 hybrid
+  int opt_sample_variant = 2;  // "sample.variant": 0 per-pixel, 1 column walker, 2 tile streamer (falls back to the walker where it does not apply)
   int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker
-  int opt_stream_rows = 32;    // "sample.srows": reduced rows per wave of the row streamer (variant 4), <= 64
-  int opt_stream_spread = 1;   // "sample.spread": consecutive streamer waves take items a quarter block apart (heavy / light mix per CU)
-  int opt_stream_hsplit = 1;   // "sample.hsplit": a heavy (fovea) tile's rows are split over this many waves (1 | 2 | 4)
-  int opt_stream_depth = 4;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 4 | 6)
+  int opt_stream_rows = 8;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64
+  int opt_stream_depth = 2;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 3 | 5)
+  int opt_stream_spread = 0;   // "sample.spread": consecutive streamer waves take tiles a quarter of the row apart instead of neighbouring ones
+  int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
@@ -190,13 +190,11 @@ struct f360_sat_decoder {
   int gw = 0, gh = 0, sw = 0, sh = 0;  // target / source geometry of the grid
   std::vector<int16_t> gx_host, gy_host;  // gw+1 / gh+1 entries
   f360::DevBuf gx_dev, gy_dev;
-  // row-streaming sampler: inverse of the x grid, largest corner step (+1, rounded to 4)
+  // tile streamer: inverse of the x grid, largest corner step (+1, rounded to 4)
   f360::DevBuf lbx_dev;
   std::vector<int> lbx_host;
   int lb_dmin = 0, lb_n = 0, halo = 0;
   bool stream_ok = false;
-  int dense_begin = 0, dense_end = 0;  // reduced columns with unit corner steps (fovea)
-  int hybrid_passes = 0;               // 0: hybrid sampler not applicable
   // fused foveation (f360_satdec_foveate_rect): per-gaze lattice maps and the compact corners
   f360::DevBuf fov_maps, fov_corners;
   // inverse-map tables of the interpolate kernel, indexed by pixel offset from

@@ -249,8 +249,8 @@ static const OptionSlot kOptions[] = {
     {"sample.rows", &f360_ctx::opt_walk_rows},
     {"sample.srows", &f360_ctx::opt_stream_rows},
     {"sample.depth", &f360_ctx::opt_stream_depth},
-    {"sample.hsplit", &f360_ctx::opt_stream_hsplit},
     {"sample.spread", &f360_ctx::opt_stream_spread},
+    {"sample.groups", &f360_ctx::opt_stream_groups},
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
@@ -277,12 +277,11 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
         F360_REQUIRE(value >= 1 && value <= 4096, "sample.rows out of range: %d", value);
       if (s.field == &f360_ctx::opt_stream_rows)
         F360_REQUIRE(value >= 1 && value <= 64, "sample.srows out of range 1..64: %d", value);
-      if (s.field == &f360_ctx::opt_stream_hsplit)
-        F360_REQUIRE(value == 1 || value == 2 || value == 4, "sample.hsplit must be 1, 2 or 4: %d",
-                     value);
       if (s.field == &f360_ctx::opt_stream_depth)
-        F360_REQUIRE(value == 2 || value == 4 || value == 6, "sample.depth must be 2, 4 or 6: %d",
+        F360_REQUIRE(value == 2 || value == 3 || value == 5, "sample.depth must be 2, 3 or 5: %d",
                      value);
+      if (s.field == &f360_ctx::opt_sample_variant)
+        F360_REQUIRE(value >= 0 && value <= 2, "sample.variant must be 0, 1 or 2: %d", value);
       ctx->*(s.field) = value;
       return F360_OK;
     }

@@ -1,48 +1,55 @@
-// sample_stream.h -- the SAT sampler as a row-streaming kernel (variant 4, the default at
-// sizes where it applies).  Included once by sat_decoder.hip, inside its anonymous namespace,
-// after SampleArgs / sample_axis / the wave-private LDS helpers.
+// sample_stream.h -- the SAT sampler as a row-streaming kernel (sample.variant 2, the default
+// where it applies).  Included once by sat_decoder.hip, inside its anonymous namespace, after
+// SampleArgs / sample_axis / udiv3_exact / the wave-private LDS helpers.
 //
 // Same arithmetic as sample_rect_kernel (src/sat_decoder_sample_rect_kernel.cl:138-241); only
 // the way the table reaches the lanes differs.  At 8K a gaze needs ~1900 table rows and every
 // 128-byte line of each, but a 12-byte gather uses 12 bytes of a 64-byte request in the
-// periphery.  Here a wave owns a 256-texel column tile of the table (3 KiB per row, a multiple
-// of both the texel and the 1 KiB a wave loads per instruction) and a RUN of reduced rows:
-//   * set-up, once per wave: the reduced pixels whose right corner lies in the tile (from the
-//     host-built inverse of the x grid, three wrap states), their LDS offsets, and -- computed
-//     by the 64 lanes in parallel -- the list of table rows the run needs (the "schedule",
-//     kept in two registers and read with v_readlane);
-//   * per scheduled row: the tile's segment (+ the halo its left corners need) travels
-//     memory -> registers (DEPTH rows in flight, branch-free clamped loads) -> wave-private LDS,
-//     the lanes pick their two corners of that row from LDS, the two corners of the row before
-//     are still in registers, and a row that closes a box produces its pixels;
-//   * pixels leave as whole 16-byte groups: a tile's pixels are one contiguous range of reduced
-//     columns, so they are packed through LDS into 4-pixel groups, merged with the destination's
-//     old bytes (the reference writes .xyz only: byte 3 and skipped pixels keep their values;
-//     the old groups are prefetched with the table rows) and stored with one 1-KiB-contiguous
-//     instruction per row.  Range ends that do not fill a group, and the rare tiles whose
-//     pixels form several ranges (frame seam), store 2 + 1 bytes per pixel instead.
-// No workgroup barrier anywhere: a wave's LDS operations execute in order.
+// periphery; here a wave owns a column tile of the table and a run of reduced rows, streams the
+// tile's segment of every table row the run needs into wave-private LDS, and the lanes pick
+// their corners there (the corners of the row before stay in registers; no workgroup barrier
+// anywhere: a wave's LDS operations execute in order).  A first version with 256-texel tiles,
+// register staging and 200 registers per wave showed what bounds such a kernel on this machine:
+// not bytes and not arithmetic but how many waves a SIMD can hold -- a lone wave issues one
+// instruction every 4+ cycles and serialises its own memory, LDS and ALU phases (s_memtime
+// stamps: 45 us per wave for a 37 us memory floor).  This one is built
+// for occupancy:
+//   * the table row segment goes memory -> LDS directly (global_load_lds_dwordx4: no staging
+//     registers, no ds_write), into a ring of NS 2 KiB slots per wave (NS - 1 rows in flight
+//     while one is consumed; a CU needs ~100 KB in flight to keep HBM busy);
+//   * a tile is 128 texels (1.5 KiB per row: one and a half load instructions, the idle half
+//     of the second carries the halo the left corners need), so a wave has at most three
+//     passes of 64 pixels per row and ~100 registers;
+//   * a wave's candidates -- the tile's main range of reduced columns, then the few pixels of
+//     the other ranges (the far periphery of the other side of the gaze wraps onto every
+//     tile) -- are packed into consecutive lanes, so a periphery tile needs ONE pass;
+//   * divisions use one reciprocal and, per channel, convert / add / multiply / convert:
+//     (n + 0.5) * (1/d) truncated is floor(n/d) exactly whenever the quotient is below 256 and
+//     d below 4096 (see ts_div); anything else in the wave takes the integer path.
+// Pixels are stored 2 + 1 bytes each by default: the reference writes .xyz only (byte 3 and
+// skipped pixels keep their values).  Option "sample.groups" = 1 stores whole 16-byte groups
+// instead -- a tile's main pixels are one contiguous range of reduced columns, so they are
+// packed through LDS into 4-pixel groups, merged with the destination's old groups (a third
+// LDS-direct load per row, 512 bytes) and stored with one 512-byte-contiguous instruction per
+// row; range ends that do not fill a group and the pixels of the other ranges still store
+// 2 + 1 bytes.  Measured equal within the noise (61.9 vs 62.0 us at 8K): the old groups cost
+// what the partial-sector writes cost.
 #pragma once
 
-constexpr int kS4Tile = 256;       // texels per tile
-constexpr int kS4MaxHalo = 64;     // texels (host checks the grid's largest step against it)
-constexpr int kS4MaxRows = 64;     // reduced rows per wave (one schedule lane per row)
-constexpr int kS4SegBytes = (kS4Tile + kS4MaxHalo) * 12;
-constexpr int kS4OutBytes = 6 * 64 * 4;  // packed pixels of one row (up to 6 passes)
-constexpr int kS4LdsBytes = kS4SegBytes + kS4OutBytes;
-
-// Output stores the compiler does not count (see global_store_b128_uncounted in
-// sat_encode.hip): scalar base + 32-bit byte offset, non-temporal.
+#ifndef F360_TS_ST_BITS
+#define F360_TS_ST_BITS " nt"  // A/B: plain stores ("") measured in profiles/round2_sampler_sweeps.txt
+#endif
 __device__ __forceinline__ void store_rgb_uncounted(uint8_t *base, uint32_t off, uint32_t rg,
                                                     uint32_t b) {
   asm volatile(
-      "global_store_short %0, %1, %3 nt\n\t"
-      "global_store_byte %0, %2, %3 offset:2 nt" ::"v"(off),
+      "global_store_short %0, %1, %3" F360_TS_ST_BITS "\n\t"
+      "global_store_byte %0, %2, %3 offset:2" F360_TS_ST_BITS ::"v"(off),
       "v"(rg), "v"(b), "s"(base)
       : "memory");
 }
 __device__ __forceinline__ void store_b128_uncounted(uint8_t *base, uint32_t off, u32x4_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base)
+  asm volatile("global_store_dwordx4 %0, %1, %2" F360_TS_ST_BITS "\n\ts_nop 1" ::"v"(off), "v"(v),
+               "s"(base)
                : "memory");
 }
 
@@ -52,12 +59,12 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
-// Two 12-byte texels (4-byte aligned) from LDS, no wait: s4_lds_wait<N>() orders the use.
-struct S4Texels {
+// Two 12-byte texels (4-byte aligned) from LDS, no wait: ts_lds_wait_all() orders the use.
+struct TsTexels {
   u32x2_t a01, b01;
   uint32_t a2, b2;
 };
-__device__ __forceinline__ void s4_lds_issue(uint32_t addr_a, uint32_t addr_b, S4Texels &t) {
+__device__ __forceinline__ void ts_lds_issue(uint32_t addr_a, uint32_t addr_b, TsTexels &t) {
   asm volatile(
       "ds_read2_b32 %0, %4 offset1:1\n\t"
       "ds_read_b32 %1, %4 offset:8\n\t"
@@ -67,187 +74,220 @@ __device__ __forceinline__ void s4_lds_issue(uint32_t addr_a, uint32_t addr_b, S
       : "v"(addr_a), "v"(addr_b)
       : "memory");
 }
+// One asm that makes every pending LDS read of the row visible: the texel registers of the N
+// passes pass through it as read-write operands, so no use can be scheduled above the wait.
+#define TS_T(i) "+v"(t[i].a01), "+v"(t[i].a2), "+v"(t[i].b01), "+v"(t[i].b2)
 template <int N>
-__device__ __forceinline__ void s4_lds_wait(S4Texels &t) {
-  asm volatile("s_waitcnt lgkmcnt(%4)"
-               : "+v"(t.a01), "+v"(t.a2), "+v"(t.b01), "+v"(t.b2)
-               : "n"(N)
-               : "memory");
+__device__ __forceinline__ void ts_lds_wait_all(TsTexels *t) {
+  static_assert(N >= 1 && N <= 5, "one to five passes");
+  if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : TS_T(0) : : "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : TS_T(0), TS_T(1) : : "memory");
+  if constexpr (N == 3)
+    asm volatile("s_waitcnt lgkmcnt(0)" : TS_T(0), TS_T(1), TS_T(2) : : "memory");
+  if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : TS_T(0), TS_T(1), TS_T(2), TS_T(3) : : "memory");
+  if constexpr (N == 5)
+    asm volatile("s_waitcnt lgkmcnt(0)" : TS_T(0), TS_T(1), TS_T(2), TS_T(3), TS_T(4) : : "memory");
+}
+#undef TS_T
+
+constexpr int kTsTile = 128;             // texels per tile
+constexpr int kTsTileVecs = 96;          // 16-byte vectors of a full tile row segment
+constexpr int kTsMaxHaloVecs = 32;       // 512 bytes = 42 texels
+// ring slot: [0,1536) tile, [1536,2048) halo (right-aligned), with "sample.groups" also
+// [2048,2560) old pixel groups
+constexpr int ts_slot_bytes(bool groups) { return groups ? 2560 : 2048; }
+constexpr int kTsStageBytes = 128 * 4 + 64 * 4;  // packed main pixels of a row + a dummy slot per lane; before that, the schedule
+constexpr int kTsPasses = 3;             // 192 candidates: 128 main + 64 others
+constexpr int kTsRanges = 5;
+constexpr int kTsMaxRows = 64;
+
+// floor(n / d) for the three channels with one reciprocal.  With inv = rcp(d) (1 ulp) the float
+// product (n + 0.5) * inv has a relative error below 2^-22; when n / d < 256 its absolute error
+// is below 2^-14, while (n + 0.5) / d keeps a distance of at least 0.5 / d > 2^-13 (d < 4096)
+// from every integer -- so truncation gives the exact quotient.  The caller checks both bounds.
+__device__ __forceinline__ uint32_t ts_div(uint32_t n, float inv) {
+  return (uint32_t)(((float)n + 0.5f) * inv);
 }
 
-// wait until at most `younger` LDS operations issued after t's are outstanding (a constant
-// once the pass loop is unrolled; the counter saturates at 15)
-__device__ __forceinline__ void s4_lds_wait_younger(int younger, S4Texels &t) {
-  switch (younger) {
-    case 0: s4_lds_wait<0>(t); break;
-    case 4: s4_lds_wait<4>(t); break;
-    case 8: s4_lds_wait<8>(t); break;
-    case 12: s4_lds_wait<12>(t); break;
-    default: s4_lds_wait<15>(t); break;
-  }
-}
+typedef const __attribute__((address_space(1))) void *ts_gptr;
+typedef __attribute__((address_space(3))) void *ts_lptr;
 
-// q = n / d, exact, for n, d < 2^22 with a shared reciprocal (1 ulp): the float product is
-// off by at most one, the exact remainder decides the correction.  24-bit multiplies.
-__device__ __forceinline__ uint32_t s4_div(uint32_t n, float inv, uint32_t d) {
-  uint32_t q = (uint32_t)((float)n * inv);
-  const uint32_t r = n - (q & 0xffffffu) * (d & 0x3fffffu);
-  if ((int32_t)r < 0) q -= 1;
-  else if (r >= d) q += 1;
-  return q;
-}
-
-template <int PASSES, int DEPTH, bool FAST>
-__device__ __forceinline__ void stream4_rows(
+// The rows of one wave: NP passes of 64 lanes, NS ring slots (NS - 1 rows in flight).  The row
+// loop is not unrolled (the ring slot is a scalar), so the whole loop is a few hundred
+// instructions of straight-line code.  FAST: the main range's whole 4-pixel groups are stored
+// as 16-byte read-modify-writes (lane L owns reduced columns fg0 + 4L .. + 3, L < nfull <= 32).
+template <int NS, bool GROUPS, int NP, bool FAST>
+__device__ __forceinline__ void tile_stream_rows(
     const SampleArgs &a, int j0, int nsched, uint32_t sched_a, uint32_t sched_b,
-    const char *sat_tile, int tile_vecs, int halo_vecs, uint32_t lds_tile, uint32_t lds_out,
-    const int (&pi)[PASSES], const int (&ci)[PASSES], const uint32_t (&off_hi)[PASSES],
-    const uint32_t (&off_lo)[PASSES], const uint32_t (&dxw)[PASSES], int fg0, int nfull) {
+    const char *row0, uint32_t off_a, uint32_t off_b, uint32_t lds0, uint8_t *lds_ptr,
+    const int (&pi)[kTsPasses], const int (&ci)[kTsPasses], const bool (&is_main)[kTsPasses],
+    const uint32_t (&off_hi)[kTsPasses], const uint32_t (&off_lo)[kTsPasses],
+    const uint32_t (&dxw)[kTsPasses], int fg0, int nfull) {
+  constexpr int kTsSlotBytes = ts_slot_bytes(GROUPS);
+  constexpr int D = NS - 1;            // rows in flight
+  constexpr int LPR = FAST ? 3 : 2;    // vector-memory loads per row
   const int lane = threadIdx.x & 63;
   const uint32_t row_bytes = (uint32_t)a.src_w * 12u;
   const uint32_t out_stride = (uint32_t)a.out_stride_px * 4u;
-  // per-lane byte offsets inside a table row (clamped: every load is issued by every lane)
-  uint32_t voff[3];
+  const uint32_t lds_stage = lds0 + NS * kTsSlotBytes;
+  const int grp = min(lane, max(nfull - 1, 0));  // lanes past the last group repeat it
+  const uint32_t grp_off = (uint32_t)(fg0 + 4 * grp) * 4u;
+  const uint32_t lds_dummy = lds_stage + 128 * 4 + (uint32_t)lane * 4u;
+  uint32_t pix_off[NP], stage_at[NP];
+  bool edge[NP], any_edge[NP], any_staged[NP], unit_p[NP];
 #pragma unroll
-  for (int v = 0; v < 3; ++v) voff[v] = (uint32_t)min(v * 64 + lane, tile_vecs - 1) * 16u;
-  const int hv = min(lane, max(halo_vecs - 1, 0));
-  const int halo_off = halo_vecs > 0 ? (hv - halo_vecs) * 16 : 0;  // bytes left of the tile
-  const bool halo_lane = lane < halo_vecs;
-  // FAST: lane L owns the 4-pixel group of reduced columns fg0 + 4L .. + 3
-  const uint32_t grp_off = (uint32_t)(fg0 + 4 * min(lane, max(nfull - 1, 0))) * 4u;
-  const bool grp_lane = lane < nfull;
-  // candidates inside the whole groups are staged (a candidate that is not written stages 0,
-  // so every slot of a group is defined); written pixels outside them are stored 2 + 1 bytes
-  bool staged[PASSES], edge[PASSES];
-  uint32_t stage_at[PASSES];
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int rel = ci[p] - fg0;
-    staged[p] = FAST && ci[p] >= 0 && rel >= 0 && rel < 4 * nfull;
-    edge[p] = pi[p] >= 0 && !staged[p];
-    stage_at[p] = lds_out + (staged[p] ? (uint32_t)rel * 4u : 0u);
+    // main-range candidates inside the whole groups are staged (one that is not written stages
+    // 0, so every slot of a group is defined); written pixels outside them store 2 + 1 bytes
+    const bool staged = FAST && is_main[p] && ci[p] >= 0 && rel >= 0 && rel < 4 * nfull;
+    stage_at[p] = staged ? lds_stage + (uint32_t)rel * 4u : lds_dummy;
+    any_staged[p] = __any(staged);
+    edge[p] = pi[p] >= 0 && !staged;
+    any_edge[p] = __any(edge[p]);
+    pix_off[p] = (uint32_t)max(pi[p], 0) * 4u;
+    unit_p[p] = __all(dxw[p] == 1);  // every box of the pass one texel wide: the fovea
   }
-  uint3 p_hi[PASSES], p_lo[PASSES];  // corners of the previous streamed row
-  bool unit_w[PASSES];               // every box of the pass is one texel wide (the fovea)
+  uint3 p_hi[NP], p_lo[NP];  // corners of the previous streamed row
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    p_hi[p] = p_lo[p] = make_uint3(0, 0, 0);
-    unit_w[p] = __all(dxw[p] == 1);
-  }
+  for (int p = 0; p < NP; ++p) p_hi[p] = p_lo[p] = make_uint3(0, 0, 0);
 
   auto entry_at = [&](int n) -> uint32_t {
     n = min(n, nsched - 1);
     return (uint32_t)__builtin_amdgcn_readlane((int)(n < 64 ? sched_a : sched_b), n & 63);
   };
-  u32x4_t regs[DEPTH][5];  // [4]: the destination's old group, FAST only
-  uint32_t ent[DEPTH];
-  auto issue = [&](int k, uint32_t entry) {
-    const char *row = sat_tile + (size_t)(entry & 0xffffu) * row_bytes;
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-      regs[k][v] = *reinterpret_cast<const u32x4_t *>(row + voff[v]);
-    regs[k][3] = *reinterpret_cast<const u32x4_t *>(row + halo_off);
+  // one row: two LDS-direct loads of 1 KiB each (+ 512 bytes of old pixel groups)
+  auto issue = [&](int slot, uint32_t entry) {
+    const char *row = row0 + (size_t)(entry & 0xffffu) * row_bytes;
+    uint8_t *dst = lds_ptr + slot * kTsSlotBytes;
+    __builtin_amdgcn_global_load_lds((ts_gptr)(row + off_a), (ts_lptr)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((ts_gptr)(row + off_b), (ts_lptr)(dst + 1024), 16, 0, 0);
     if (FAST) {
       const int rsel = (int)(entry >> 24);
       const uint32_t row_off = (uint32_t)(j0 + max(rsel - 1, 0)) * out_stride;
-      regs[k][4] = *reinterpret_cast<const u32x4_t *>(a.dst + row_off + grp_off);
+      if (lane < 32)
+        __builtin_amdgcn_global_load_lds((ts_gptr)(a.dst + row_off + grp_off),
+                                         (ts_lptr)(dst + 2048), 16, 0, 0);
     }
   };
 #pragma unroll
-  for (int k = 0; k < DEPTH; ++k) {
-    ent[k] = entry_at(k);
-    issue(k, ent[k]);
-    // keeps the rows' loads in issue order: the wait for row n counts the loads younger than it,
-    // and a reordered prologue would turn the loop's first wait into vmcnt(0)
-    asm volatile("" ::: "memory");
-  }
-  for (int n0 = 0; n0 < nsched; n0 += DEPTH) {
+  for (int k = 0; k < D; ++k) issue(k, entry_at(k));
+  int slot = 0, slot_pf = D;  // slot of row n, slot the row n + D goes to (row n - 1 has left it)
+  for (int n = 0; n < nsched; ++n) {
+    const uint32_t cur = entry_at(n);
+    issue(slot_pf, entry_at(n + D));
+    // all but the loads of the D younger rows have landed.  (Loads and stores retire from vmcnt
+    // in issue order on gfx950 -- tools/vmcnt_order -- so the stores issued meanwhile could be
+    // counted too; selecting the immediate at run time cost more than the stricter wait.)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * LPR) : "memory");
+    const uint32_t slot_base = lds0 + (uint32_t)slot * kTsSlotBytes;
+    slot = slot + 1 == NS ? 0 : slot + 1;
+    slot_pf = slot_pf + 1 == NS ? 0 : slot_pf + 1;
+    TsTexels t[NP];
 #pragma unroll
-    for (int k = 0; k < DEPTH; ++k) {
-      const int n = n0 + k;
-      const uint32_t cur = ent[k];
+    for (int p = 0; p < NP; ++p) ts_lds_issue(slot_base + off_hi[p], slot_base + off_lo[p], t[p]);
+    ts_lds_wait_all<NP>(t);
+    const uint32_t dy = (cur >> 16) & 0xffu;
+    const int rsel = (int)(cur >> 24);  // 0: top corners only
+    const uint32_t row_off = (uint32_t)(j0 + rsel - 1) * out_stride;
+    uint3 hi[NP], lo[NP];
 #pragma unroll
-      for (int v = 0; v < 3; ++v)
-        if (v * 64 + lane < tile_vecs)
-          lds_store16(lds_tile + (uint32_t)(v * 64 + lane) * 16u, regs[k][v]);
-      if (halo_lane) lds_store16(lds_tile + (uint32_t)halo_off, regs[k][3]);
-      u32x4_t old = {0, 0, 0, 0};
-      if (FAST) old = regs[k][4];
-      ent[k] = entry_at(n + DEPTH);
-      issue(k, ent[k]);
-      if (n >= nsched) continue;
-      S4Texels t[PASSES];
+    for (int p = 0; p < NP; ++p) {
+      hi[p] = make_uint3(t[p].a01.x, t[p].a01.y, t[p].a2);
+      lo[p] = make_uint3(t[p].b01.x, t[p].b01.y, t[p].b2);
+    }
+    if (rsel != 0 && !(a.ablate & 32)) {
+      uint3 s[NP];
+      uint32_t d[NP];
+      bool slow = false;
 #pragma unroll
-      for (int p = 0; p < PASSES; ++p) s4_lds_issue(off_hi[p], off_lo[p], t[p]);
-      const uint32_t dy = (cur >> 16) & 0xffu;
-      const int rsel = (int)(cur >> 24);  // 0: top corners only
-      const uint32_t row_off = (uint32_t)(j0 + rsel - 1) * out_stride;
-      const bool emit = rsel != 0 && !(a.ablate & 32);
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        s4_lds_wait_younger(4 * (PASSES - 1 - p), t[p]);
-        const uint3 hi = make_uint3(t[p].a01.x, t[p].a01.y, t[p].a2);
-        const uint3 lo = make_uint3(t[p].b01.x, t[p].b01.y, t[p].b2);
-        if (emit) {
-          uint3 s = make_uint3(hi.x - p_hi[p].x + p_lo[p].x - lo.x,
-                               hi.y - p_hi[p].y + p_lo[p].y - lo.y,
-                               hi.z - p_hi[p].z + p_lo[p].z - lo.z);
-          const uint32_t d = dxw[p] * dy;
-          uint3 q;
-          if (unit_w[p] && dy == 1) {
-            q = s;  // 1x1 boxes: more than half of the pixels at the benchmark geometries
-          } else if (__builtin_expect(__any(((s.x | s.y | s.z | d) >> 22) != 0), 0)) {
-            q = udiv3_exact(s, d);  // a wrapped table read with a degenerate box
-          } else {
-            const float inv = __builtin_amdgcn_rcpf((float)d);
-            q = make_uint3(s4_div(s.x, inv, d), s4_div(s.y, inv, d), s4_div(s.z, inv, d));
-          }
-          const uint32_t rg = (q.x & 0xffu) | ((q.y & 0xffu) << 8);
-          if (FAST && staged[p])  // 0xff in byte 3 marks a pixel that is written
-            lds_store4(stage_at[p], pi[p] >= 0 ? (rg | ((q.z & 0xffu) << 16) | 0xff000000u) : 0u);
-          if (edge[p] && !(a.ablate & 16))
-            store_rgb_uncounted(a.dst, row_off + (uint32_t)pi[p] * 4u, rg, q.z);
-        }
-        p_hi[p] = hi;
-        p_lo[p] = lo;
+      for (int p = 0; p < NP; ++p) {
+        s[p] = make_uint3(hi[p].x - p_hi[p].x + p_lo[p].x - lo[p].x,
+                          hi[p].y - p_hi[p].y + p_lo[p].y - lo[p].y,
+                          hi[p].z - p_hi[p].z + p_lo[p].z - lo[p].z);
+        d[p] = dxw[p] * dy;
+        // the float quotient is exact for quotients < 256 and d < 4096
+        const uint32_t lim = d[p] << 8;
+        slow = slow || s[p].x >= lim || s[p].y >= lim || s[p].z >= lim || d[p] >= 4096u;
       }
-      if (FAST && emit) {
-        u32x4_t px;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(px)
-                     : "v"(lds_out + (uint32_t)lane * 16u)
-                     : "memory");
+      uint3 q[NP];
+      if (__builtin_expect(__any(slow), 0)) {
+        // a wrapped table read with a degenerate box somewhere in the wave: integer division
+#pragma unroll
+        for (int p = 0; p < NP; ++p) q[p] = udiv3_exact(s[p], d[p]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          if (unit_p[p] && dy == 1) {  // 1x1 boxes: most pixels of the fovea
+            q[p] = s[p];
+          } else {
+            const float inv = __builtin_amdgcn_rcpf((float)d[p]);
+            q[p] = make_uint3(ts_div(s[p].x, inv), ts_div(s[p].y, inv), ts_div(s[p].z, inv));
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const uint32_t rg = (q[p].x & 0xffu) | ((q[p].y & 0xffu) << 8);
+        if (FAST && any_staged[p])  // 0xff in byte 3 marks a pixel that is written
+          lds_store4(stage_at[p], pi[p] >= 0 ? (rg | ((q[p].z & 0xffu) << 16) | 0xff000000u) : 0u);
+        if (any_edge[p] && !(a.ablate & 16)) {
+          if (edge[p]) store_rgb_uncounted(a.dst, row_off + pix_off[p], rg, q[p].z);
+        }
+      }
+      if (FAST) {
+        u32x4_t px, old;
+        asm volatile(
+            "ds_read_b128 %0, %2\n\t"
+            "ds_read_b128 %1, %3\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(px), "=&v"(old)
+            : "v"(lds_stage + (uint32_t)grp * 16u), "v"(slot_base + 2048u + (uint32_t)grp * 16u)
+            : "memory");
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const uint32_t m = (uint32_t)((int32_t)px[c] >> 31) & 0x00ffffffu;
           old[c] = (px[c] & m) | (old[c] & ~m);
         }
-        if (grp_lane && !(a.ablate & 16)) store_b128_uncounted(a.dst, row_off + grp_off, old);
+        if (!(a.ablate & 16)) store_b128_uncounted(a.dst, row_off + grp_off, old);
       }
     }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      p_hi[p] = hi[p];
+      p_lo[p] = lo[p];
+    }
   }
+  // nothing may still be landing in this wave's LDS when the workgroup's allocation is reused
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int PASSES, int DEPTH>
-__device__ __forceinline__ void stream4_body(const SampleArgs &a, int tile, int j0, int rows,
-                                             uint32_t lds0) {
+template <int NS, bool GROUPS>
+__device__ __forceinline__ void tile_stream_body(const SampleArgs &a, int tile, int j0, int rows,
+                                             uint32_t lds0, uint8_t *lds_ptr) {
   const int lane = threadIdx.x & 63;
   const int src_w = a.src_w;
-  const int ntiles = (src_w + kS4Tile - 1) / kS4Tile;
-  const uint32_t lds_tile = lds0 + kS4MaxHalo * 12;  // LDS address of texel x_tile
-  const uint32_t lds_out = lds0 + kS4SegBytes;
-  const int x_tile = tile * kS4Tile;
+  const int ntiles = (src_w + kTsTile - 1) / kTsTile;
+  constexpr int kTsSlotBytes = ts_slot_bytes(GROUPS);
+  const uint32_t lds_stage = lds0 + NS * kTsSlotBytes;  // the schedule is built here
+  const int x_tile = tile * kTsTile;
 
-  // ---- candidate pixels: wrap states k = 0, +1, -1, each a contiguous range of columns
-  int cnt[3], first[3];
+  // ---- candidate pixels: contiguous ranges of reduced columns whose unwrapped right corner
+  // cxp + gx[i+1] lies in the tile's window -- wrap states k = 0, +1, -1 (the log-rectilinear
+  // lattice spans +-W around the gaze, so the far periphery of the other side lands on every
+  // tile), and for the last tile the pixels that straddle the seam (their corner is clamped
+  // back to src_w - 1; wrap states 0 and +1, a box that was moved up by W cannot straddle).
+  // A corner clamped up to 1 was 0: inside the first tile anyway.
+  int cnt[kTsRanges], first[kTsRanges];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int k = q == 0 ? 0 : (q == 1 ? 1 : -1);
-    // unwrapped right corner cxp + gx[i+1] in [lo_b, hi_b); the last tile also takes the
-    // pixels that straddle the seam (their corner is clamped back to src_w - 1); a corner
-    // clamped up to 1 was 0, inside the first tile anyway
-    const int lo_b = x_tile + k * src_w - a.cxp;
-    const int hi_b = lo_b + kS4Tile + (tile == ntiles - 1 ? a.halo : 0);
+  for (int q = 0; q < kTsRanges; ++q) {
+    const int k = (q == 1 || q == 4) ? 1 : (q == 2 ? -1 : 0);
+    int lo_b = x_tile + k * src_w - a.cxp, hi_b = lo_b + kTsTile;
+    if (q >= 3) {
+      lo_b = hi_b;
+      hi_b = lo_b + (tile == ntiles - 1 ? a.halo : 0);
+    }
     const int g_lo = a.lbx[min(max(lo_b - a.lb_dmin, 0), a.lb_n - 1)];
     const int g_hi = a.lbx[min(max(hi_b - a.lb_dmin, 0), a.lb_n - 1)];
     const int i_lo = max(g_lo - 1, 0);  // grid index g is the right corner of pixel g - 1
@@ -255,47 +295,64 @@ __device__ __forceinline__ void stream4_body(const SampleArgs &a, int tile, int 
     first[q] = i_lo;
     cnt[q] = i_hi - i_lo;
   }
-  const int total = cnt[0] + cnt[1] + cnt[2];
-  if (total == 0) return;
-
-  int pi[PASSES];  // reduced column this wave writes, -1: none
-  int ci[PASSES];  // candidate column (written or not), -1: none
-  uint32_t off_hi[PASSES], off_lo[PASSES], dxw[PASSES];
-  int need_halo = 0;
-  bool any_mine = false, foreign = false;
-  // every pass's grid loads are issued before anything depends on one (clamped indices, no
-  // load inside a branch: the set-up is one memory round trip, not one per pass)
-  int16_t g_hi[PASSES], g_lo[PASSES];
+  // main range = the largest (the host guarantees <= 128, and the others <= 64 in all); the
+  // candidate list is the main range followed by the others
+  int m = 0;
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
+  for (int q = 1; q < kTsRanges; ++q)
+    if (cnt[q] > cnt[m]) m = q;
+  int cnt_main = 0, first_main = 0;
+#pragma unroll
+  for (int q = 0; q < kTsRanges; ++q)
+    if (q == m) {
+      cnt_main = cnt[q];
+      first_main = first[q];
+      cnt[q] = 0;  // what remains in cnt[] are the other ranges
+    }
+  const int total = cnt_main + cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4];
+  if (total == 0) return;
+  const int np = (total + 63) >> 6;
+
+  int pi[kTsPasses];       // reduced column this wave writes, -1: none
+  int ci[kTsPasses];       // candidate column (written or not), -1: none
+  bool is_main[kTsPasses];
+  int16_t g_hi[kTsPasses], g_lo[kTsPasses];
+  // every pass's grid loads are issued before anything depends on one (clamped indices, no
+  // load inside a branch: the set-up is one memory round trip)
+#pragma unroll
+  for (int p = 0; p < kTsPasses; ++p) {
     int q = p * 64 + lane;
     int i = -1;
+    is_main[p] = q < cnt_main;
+    if (is_main[p]) {
+      i = first_main + q;
+    } else {
+      q -= cnt_main;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (i < 0 && q >= 0 && q < cnt[s]) i = first[s] + q;
-      q -= cnt[s];
+      for (int s = 0; s < kTsRanges; ++s) {
+        if (i < 0 && q >= 0 && q < cnt[s]) i = first[s] + q;
+        q -= cnt[s];
+      }
     }
     ci[p] = i;
     const int ic = min(max(i, 0), a.out_w - 1);
     g_hi[p] = a.gx[ic + 1];
     g_lo[p] = a.gx[ic];
   }
+  AxisBox bx[kTsPasses];
+  int need_halo = 0;
+  bool any_mine = false, foreign = false;
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
+  for (int p = 0; p < kTsPasses; ++p) {
     pi[p] = -1;
-    off_hi[p] = off_lo[p] = lds_tile;
-    dxw[p] = 1;
+    bx[p] = sample_axis(a.cxp, g_hi[p], g_lo[p], src_w, true);
     if (ci[p] >= 0) {
-      const AxisBox bx = sample_axis(a.cxp, g_hi[p], g_lo[p], src_w, true);
-      if (bx.ok && bx.hi >= x_tile && bx.hi < x_tile + kS4Tile) {
+      if (bx[p].ok && bx[p].hi >= x_tile && bx[p].hi < x_tile + kTsTile) {
         pi[p] = ci[p];
-        off_hi[p] = lds_tile + (uint32_t)(bx.hi - x_tile) * 12u;
-        off_lo[p] = lds_tile + (uint32_t)((bx.lo - x_tile) * 12);  // may lie in the halo
-        dxw[p] = (uint32_t)(bx.hi - bx.lo);
-        need_halo = max(need_halo, x_tile - bx.lo);
+        need_halo = max(need_halo, x_tile - bx[p].lo);
         any_mine = true;
-      } else if (bx.ok) {
-        foreign = true;  // another tile's pixel inside this tile's candidate range
+      } else if (bx[p].ok && is_main[p]) {
+        foreign = true;  // another tile's pixel inside this tile's main range
       }
     }
   }
@@ -303,7 +360,20 @@ __device__ __forceinline__ void stream4_body(const SampleArgs &a, int tile, int 
   // halo of this tile in 16-byte vectors (4 texels = 3 vectors), never reaching below x = 0
   const int halo_vecs = __builtin_amdgcn_readfirstlane(
       min((wave_max_i32(need_halo) + 3) / 4 * 3, x_tile * 3 / 4));
-  const int tile_vecs = (min(x_tile + kS4Tile, src_w) - x_tile) * 3 / 4;  // width % 4 == 0
+  const int hb = halo_vecs * 16;
+  const int tile_vecs = (min(x_tile + kTsTile, src_w) - x_tile) * 3 / 4;  // width % 4 == 0
+  uint32_t off_hi[kTsPasses], off_lo[kTsPasses], dxw[kTsPasses];
+#pragma unroll
+  for (int p = 0; p < kTsPasses; ++p) {
+    off_hi[p] = off_lo[p] = 0;
+    dxw[p] = 1;
+    if (pi[p] >= 0) {
+      off_hi[p] = (uint32_t)(bx[p].hi - x_tile) * 12u;
+      const int dl = bx[p].lo - x_tile;  // < 0: in the halo, stored right-aligned behind the tile
+      off_lo[p] = dl >= 0 ? (uint32_t)dl * 12u : (uint32_t)(kTsTileVecs * 16 + hb + dl * 12);
+      dxw[p] = (uint32_t)(bx[p].hi - bx[p].lo);
+    }
+  }
 
   // ---- schedule: lane r owns reduced row j0 + r.  entry = table row | box height << 16 |
   // (r + 1) << 24, the last field 0 for a row that only provides the top corners of the box
@@ -320,66 +390,61 @@ __device__ __forceinline__ void stream4_body(const SampleArgs &a, int tile, int 
     const unsigned long long m_ok = __ballot(ok), m_top = __ballot(top);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int pos = __popcll(m_ok & below) + __popcll(m_top & below);
-    if (top) lds_store4(lds_out + 4 * pos, (uint32_t)by.lo);
+    if (top) lds_store4(lds_stage + 4 * pos, (uint32_t)by.lo);
     if (ok)
-      lds_store4(lds_out + 4 * (pos + (top ? 1 : 0)),
+      lds_store4(lds_stage + 4 * (pos + (top ? 1 : 0)),
                  (uint32_t)by.hi | ((uint32_t)(by.hi - by.lo) << 16) | ((uint32_t)(lane + 1) << 24));
     nsched = __popcll(m_ok) + __popcll(m_top);
-    sched_a = lds_load4(lds_out + 4 * lane);         // entries 0..63  (stale beyond nsched:
-    sched_b = lds_load4(lds_out + 4 * (64 + lane));  // entries 64..127 never selected)
+    sched_a = lds_load4(lds_stage + 4 * lane);         // entries 0..63  (stale beyond nsched:
+    sched_b = lds_load4(lds_stage + 4 * (64 + lane));  // entries 64..127 never selected)
   }
   if (nsched == 0) return;
 
-  const char *sat_tile = reinterpret_cast<const char *>(a.sat) + (size_t)x_tile * 12;
-  // whole-group stores need ONE range of candidates and no foreign pixel in it
-  const int nranges = (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0);
-  const int ia = cnt[0] > 0 ? first[0] : (cnt[1] > 0 ? first[1] : first[2]);
-  const int fg0 = (ia + 3) & ~3;
-  const int nfull = min((ia + total - fg0) >> 2, 64);  // one group per lane
-  if (nranges == 1 && !__any(foreign) && nfull >= 1 && !(a.ablate & 64))
-    stream4_rows<PASSES, DEPTH, true>(a, j0, nsched, sched_a, sched_b, sat_tile, tile_vecs,
-                                      halo_vecs, lds_tile, lds_out, pi, ci, off_hi, off_lo, dxw,
-                                      fg0, nfull);
+  // ---- per-lane source offsets of the two loads of a row, relative to row0 = table +
+  // x_tile * 12 - 512 (so that the halo's offsets are not negative; tile 0 has no halo and
+  // never goes below its own start)
+  const char *row0 = reinterpret_cast<const char *>(a.sat) + (size_t)x_tile * 12 - 512;
+  const uint32_t off_a = 512u + (uint32_t)min(lane, tile_vecs - 1) * 16u;
+  uint32_t off_b;
+  if (lane < 32)
+    off_b = 512u + (uint32_t)min(64 + lane, tile_vecs - 1) * 16u;
   else
-    stream4_rows<PASSES, DEPTH, false>(a, j0, nsched, sched_a, sched_b, sat_tile, tile_vecs,
-                                       halo_vecs, lds_tile, lds_out, pi, ci, off_hi, off_lo, dxw,
-                                       0, 0);
+    off_b = halo_vecs > 0 ? (uint32_t)(512 - hb + min(lane - 32, halo_vecs - 1) * 16) : 512u;
+
+  // whole-group stores need a main range without foreign pixels and at least one whole group
+  const int fg0 = (first_main + 3) & ~3;
+  const int nfull = min((first_main + cnt_main - fg0) >> 2, 32);
+  const bool fast = GROUPS && !__any(foreign) && nfull >= 1;
+#define TS_ROWS(N, F)                                                                        \
+  tile_stream_rows<NS, GROUPS, N, F>(a, j0, nsched, sched_a, sched_b, row0, off_a, off_b, lds0, lds_ptr, \
+                         pi, ci, is_main, off_hi, off_lo, dxw, F ? fg0 : 0, F ? nfull : 0)
+  if (GROUPS && fast) {
+    if (np <= 1) TS_ROWS(1, GROUPS);
+    else if (np == 2) TS_ROWS(2, GROUPS);
+    else TS_ROWS(3, GROUPS);
+  } else {
+    if (np <= 1) TS_ROWS(1, false);
+    else if (np == 2) TS_ROWS(2, false);
+    else TS_ROWS(3, false);
+  }
+#undef TS_ROWS
 }
 
-// Work items.  The frame's reduced rows are cut into blocks of `rows`; inside a block a light
-// (periphery) tile is one item, a heavy tile -- one that overlaps the fovea's unit-step columns:
-// four passes per row instead of one -- is `hsplit` items of rows / hsplit rows each, so that
-// items carry about the same instruction count and no wave is the kernel's critical path.
-// Heavy tiles are `th` consecutive tiles starting at `rot` (mod the tile count); any 0 <= th <=
-// ntiles covers every (tile, row) exactly once.  Consecutive waves take items `istride` apart
-// (coprime to the items of a block, about a quarter of them): the four waves of a workgroup --
-// and with them every CU and SIMD, since all waves of the launch are resident at once and
-// nothing rebalances them -- get the same mix of heavy and light items.
-template <int PASSES, int DEPTH>
-__global__ __launch_bounds__(256) void sample_rect_stream4_kernel(const SampleArgs a, int rows,
-                                                                  int nblocks, int hsplit,
-                                                                  int th, int rot, int istride) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[4][kS4LdsBytes];
+// Work items = (row block, tile); consecutive waves take tiles `istride` apart (coprime to the
+// tile count, about a quarter of it), so the four waves of a workgroup -- and with them every
+// CU -- get the same mix of fovea and periphery tiles.
+template <int NS, bool GROUPS>
+__global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArgs a, int rows,
+                                                                  int nblocks, int rot,
+                                                                  int istride) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[4][NS * ts_slot_bytes(GROUPS) + kTsStageBytes];
   const int wave = threadIdx.x >> 6;
-  const int ntiles = (a.src_w + kS4Tile - 1) / kS4Tile;
-  const int per_block = hsplit * th + (ntiles - th);
+  const int ntiles = (a.src_w + kTsTile - 1) / kTsTile;
   const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
-  if (g >= per_block * nblocks) return;
-  const int blk = g / per_block;
-  const int r = (int)(((unsigned)(g - blk * per_block) * (unsigned)istride) % (unsigned)per_block);
-  int t, j0, nrows;
-  if (r < hsplit * th) {
-    t = r / hsplit;
-    nrows = rows / hsplit;
-    j0 = blk * rows + (r - t * hsplit) * nrows;
-  } else {
-    t = th + (r - hsplit * th);
-    nrows = rows;
-    j0 = blk * rows;
-  }
-  t += rot;
+  if (g >= ntiles * nblocks) return;
+  const int blk = g / ntiles;
+  int t = (int)(((unsigned)(g - blk * ntiles) * (unsigned)istride) % (unsigned)ntiles) + rot;
   if (t >= ntiles) t -= ntiles;
-  if (j0 >= a.out_h) return;
-  stream4_body<PASSES, DEPTH>(a, t, j0, nrows,
-                              (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]));
+  tile_stream_body<NS, GROUPS>(a, t, blk * rows, rows,
+                   (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]), &stage[wave][0]);
 }

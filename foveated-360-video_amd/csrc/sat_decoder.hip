@@ -129,11 +129,10 @@ struct SampleArgs {
   int src_w, src_h;
   const int16_t *gx, *gy;
   int cxp, cyp;
-  // row-streaming / hybrid
+  // tile streamer: inverse of the x grid (lbx[d - lb_dmin] = first grid index whose offset is
+  // >= d), largest corner step (+1, rounded to 4)
   const int *lbx;
   int lb_dmin, lb_n, halo;
-  int dense_begin, dense_end;  // reduced columns [begin, end) with unit steps (the fovea)
-  int walk_blocks;             // hybrid: blockIdx.x below this runs the walker
   int ablate;                  // timing experiments only
   int reverse;                 // visit the row runs bottom-up (the table's last rows are the
                                // most recently written, hence the likeliest to be cached)
@@ -261,32 +260,13 @@ __global__ __launch_bounds__(256) void sample_rect_walk_batch_kernel(SampleArgs 
   walk_body(a, c0, 0, a.out_w, j0, min(j0 + rows, a.out_h));
 }
 
-// Variant 2 ("row streaming").  At 8K a gaze touches ~1900 table rows and every
-// 128-byte line of each of them, yet a gather uses 12 bytes of each 64-byte
-// request in the periphery.  Here a wave owns a 256-texel source tile and a run
-// of reduced rows: it streams the tile's segment of every table row the run
-// needs with coalesced 16-byte loads into wave-private LDS, and the lanes pick
-// their corners from LDS.  A reduced pixel belongs to the tile that contains
-// its (wrapped, clamped) right corner, so every pixel is produced exactly once;
-// its left corner lies at most `halo` texels to the left, inside the segment
-// (a corner that is not is fetched from memory, so the result is the
-// reference's regardless).  The candidate pixels of a tile come from a
-// host-built inverse of the x grid: lbx[d] = first grid index with offset >= d.
-// Variant 3 ("hybrid") gives the fovea's unit-step columns, where gathers are
-// already contiguous, to the walker and streams only the periphery.
-constexpr int kTileTexels = 256;
-constexpr int kMaxHalo = 64;
-constexpr int kStreamRows = 8;  // reduced rows per wave
-
+// Variant 2 ("tile streamer") lives in sample_stream.h.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 // Wave-private LDS exchange goes through inline asm: the compiler's memory
 // model is per lane and it deletes plain LDS stores that only OTHER lanes read.
 // One wave's LDS operations execute in order, so no barrier is needed.
-__device__ __forceinline__ void lds_store16(uint32_t addr, u32x4_t v) {
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
 __device__ __forceinline__ void lds_store4(uint32_t addr, uint32_t v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -294,188 +274,6 @@ __device__ __forceinline__ uint32_t lds_load4(uint32_t addr) {
   uint32_t v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
   return v;
-}
-// two 12-byte texels (4-byte aligned) with one wait
-__device__ __forceinline__ void lds_load_texels(uint32_t addr_a, uint32_t addr_b, uint3 &a,
-                                                uint3 &b) {
-  u32x2_t a01, b01;
-  uint32_t a2, b2;
-  asm volatile(
-      "ds_read2_b32 %0, %4 offset1:1\n\t"
-      "ds_read_b32 %1, %4 offset:8\n\t"
-      "ds_read2_b32 %2, %5 offset1:1\n\t"
-      "ds_read_b32 %3, %5 offset:8\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(a01), "=&v"(a2), "=&v"(b01), "=&v"(b2)
-      : "v"(addr_a), "v"(addr_b)
-      : "memory");
-  a = make_uint3(a01.x, a01.y, a2);
-  b = make_uint3(b01.x, b01.y, b2);
-}
-
-constexpr int kStageDwords = (kTileTexels + kMaxHalo) * 3 + 2 * kStreamRows + 4;
-
-// One wave: source tile `tile`, reduced rows [j0, j0 + kStreamRows); reduced columns in
-// [a.dense_begin, a.dense_end) are somebody else's.  `lds0` is this wave's LDS region.
-template <int PASSES>
-__device__ __forceinline__ void stream_body(const SampleArgs &a, int tile, int j0,
-                                            uint32_t lds0) {
-  const int lane = threadIdx.x & 63;
-  const int src_w = a.src_w;
-  const int ntiles = (src_w + kTileTexels - 1) / kTileTexels;
-  const uint32_t lds_sched = lds0 + (kTileTexels + kMaxHalo) * 12;
-
-  // ---- the tile's segment of a table row
-  const int x_tile = tile * kTileTexels;
-  const int seg_x0 = max(x_tile - a.halo, 0);
-  const int seg_x1 = min(x_tile + kTileTexels, src_w);
-  const int seg_vec = (seg_x1 - seg_x0) * 3 / 4;  // 16-byte vectors; width % 4 == 0
-
-  // ---- candidate pixels: wrap states k = 0, +1, -1; each a contiguous column range, cut
-  // in two by the excluded dense range
-  int cnt[6], first[6];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int k = q == 0 ? 0 : (q == 1 ? 1 : -1);
-    // unwrapped right corner cxp + gx[i+1] in [lo_b, hi_b); the last tile also takes the
-    // pixels that straddle the seam (their corner is clamped back to src_w - 1)
-    const int lo_b = x_tile + k * src_w - a.cxp;
-    const int hi_b = lo_b + kTileTexels + (tile == ntiles - 1 ? a.halo : 0);
-    const int g_lo = a.lbx[min(max(lo_b - a.lb_dmin, 0), a.lb_n - 1)];
-    const int g_hi = a.lbx[min(max(hi_b - a.lb_dmin, 0), a.lb_n - 1)];
-    const int i_lo = max(g_lo - 1, 0);  // grid index g is the right corner of pixel g - 1
-    const int i_hi = max(min(g_hi - 1, a.out_w), i_lo);
-    first[2 * q] = i_lo;
-    cnt[2 * q] = max(min(i_hi, a.dense_begin) - i_lo, 0);
-    first[2 * q + 1] = max(i_lo, a.dense_end);
-    cnt[2 * q + 1] = max(i_hi - first[2 * q + 1], 0);
-  }
-  int total = 0;
-#pragma unroll
-  for (int q = 0; q < 6; ++q) total += cnt[q];
-  if (total == 0) return;
-  const int npass = (total + 63) / 64;  // the host guarantees <= PASSES
-
-  // ---- schedule (in LDS, it is indexed dynamically): the table rows to stream.
-  // entry = row | box height << 16 | (reduced row - j0 + 1) << 24, the last field
-  // 0 for a row that only provides the top corners of the next box
-  int nsched = 0;
-  {
-    int prev = -1;
-    for (int r = 0; r < kStreamRows; ++r) {
-      const int j = j0 + r;
-      if (j >= a.out_h) break;
-      const AxisBox by = sample_axis(a.cyp, a.gy[j + 1], a.gy[j], a.src_h, false);
-      if (!by.ok) continue;
-      if (by.lo != prev) {
-        if (lane == 0) lds_store4(lds_sched + 4 * nsched, (uint32_t)by.lo);
-        ++nsched;
-      }
-      if (lane == 0)
-        lds_store4(lds_sched + 4 * nsched, (uint32_t)by.hi | ((uint32_t)(by.hi - by.lo) << 16) |
-                                               ((uint32_t)(r + 1) << 24));
-      ++nsched;
-      prev = by.hi;
-    }
-  }
-  if (nsched == 0) return;
-
-  int pi[PASSES];                        // reduced column, -1: no pixel
-  uint32_t off_hi[PASSES], off_lo[PASSES], dxw[PASSES];
-  int lo_x[PASSES];                      // >= 0: left corner lies outside the segment
-  uint3 p_hi[PASSES], p_lo[PASSES];      // corners of the previous streamed row
-  bool any_mine = false;
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    pi[p] = -1;
-    off_hi[p] = off_lo[p] = 0;
-    dxw[p] = 1;
-    lo_x[p] = -1;
-    p_hi[p] = p_lo[p] = make_uint3(0, 0, 0);
-    if (p < npass) {
-      int q = p * 64 + lane;
-      int i = -1;
-#pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        if (i < 0 && q >= 0 && q < cnt[s]) i = first[s] + q;
-        q -= cnt[s];
-      }
-      if (i >= 0) {
-        const AxisBox bx = sample_axis(a.cxp, a.gx[i + 1], a.gx[i], src_w, true);
-        if (bx.ok && bx.hi >= x_tile && bx.hi < x_tile + kTileTexels) {
-          pi[p] = i;
-          off_hi[p] = (uint32_t)(bx.hi - seg_x0) * 12u;
-          dxw[p] = (uint32_t)(bx.hi - bx.lo);
-          if (bx.lo >= seg_x0) off_lo[p] = (uint32_t)(bx.lo - seg_x0) * 12u;
-          else lo_x[p] = bx.lo;
-          any_mine = true;
-        }
-      }
-    }
-  }
-  if (!__any(any_mine)) return;
-
-  // ---- stream: row n+1 travels from memory while row n is consumed from LDS
-  u32x4_t regs[4];
-  auto issue_loads = [&](int y) {
-    const u32x4_t *row =
-        reinterpret_cast<const u32x4_t *>(a.sat + ((size_t)y * src_w + seg_x0) * 3);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) regs[v] = row[min(v * 64 + lane, seg_vec - 1)];
-  };
-  uint32_t entry = __builtin_amdgcn_readfirstlane(lds_load4(lds_sched));
-  issue_loads((int)(entry & 0xffffu));
-  for (int n = 0; n < nsched; ++n) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-      if (v * 64 + lane < seg_vec) lds_store16(lds0 + (uint32_t)(v * 64 + lane) * 16u, regs[v]);
-    const uint32_t cur = entry;
-    if (n + 1 < nsched) {
-      entry = __builtin_amdgcn_readfirstlane(lds_load4(lds_sched + 4 * (n + 1)));
-      issue_loads((int)(entry & 0xffffu));
-    }
-    const int y = (int)(cur & 0xffffu);
-    const uint32_t dy = (cur >> 16) & 0xffu;
-    const int rsel = (int)(cur >> 24);  // 0: top corners only
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      if (p >= npass) break;
-      uint3 hi, lo;
-      lds_load_texels(lds0 + off_hi[p], lds0 + off_lo[p], hi, lo);
-      if (lo_x[p] >= 0) lo = load_sat3(a.sat, (size_t)y * src_w + lo_x[p]);
-      if (rsel != 0 && pi[p] >= 0) {
-        const uint3 q = udiv3_exact(
-            make_uint3(hi.x - p_hi[p].x + p_lo[p].x - lo.x, hi.y - p_hi[p].y + p_lo[p].y - lo.y,
-                       hi.z - p_hi[p].z + p_lo[p].z - lo.z),
-            dxw[p] * dy);
-        store_rgb(a.dst + ((size_t)(j0 + rsel - 1) * a.out_stride_px + pi[p]) * 4, q.x, q.y,
-                  q.z);
-      }
-      p_hi[p] = hi;
-      p_lo[p] = lo;
-    }
-  }
-}
-
-template <int PASSES>
-__global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t stage[4][kStageDwords];
-  const int wave = threadIdx.x >> 6;
-  const int by = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
-  const int j0 = by * kStreamRows;
-  if ((int)blockIdx.x < a.walk_blocks) {  // hybrid only: the fovea's columns by gathers
-    if (a.ablate & 4) return;
-    const int c0 = __builtin_amdgcn_readfirstlane(a.dense_begin +
-                                                  ((int)blockIdx.x * 4 + wave) * kWalkCols);
-    if (c0 >= a.dense_end) return;
-    walk_body(a, c0, a.dense_begin, a.dense_end, j0, min(j0 + kStreamRows, a.out_h));
-    return;
-  }
-  if (a.ablate & 8) return;
-  const int tile =
-      __builtin_amdgcn_readfirstlane(((int)blockIdx.x - a.walk_blocks) * 4 + wave);
-  if (tile >= (a.src_w + kTileTexels - 1) / kTileTexels) return;
-  stream_body<PASSES>(a, tile, j0, (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]));
 }
 
 #include "sample_stream.h"
@@ -962,66 +760,26 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
   st = upload(dec->ctx, dec->gy_dev, dec->gy_host.data(),
               dec->gy_host.size() * sizeof(int16_t));
   if (st != F360_OK) return st;
-  // inverse of the x grid for the row-streaming sampler: lbx[d - dmin] = first grid
-  // index whose offset is >= d; plus the largest step between neighbouring corners
+  // inverse of the x grid for the tile streamer: lbx[d - dmin] = first grid index whose
+  // offset is >= d; plus the largest step between neighbouring corners (its halo)
   {
     const std::vector<int16_t> &g = dec->gx_host;
     const int dmin = g.front(), dmax = g.back() + 1;
     std::vector<int> lb((size_t)(dmax - dmin + 1));
     size_t gi = 0;
-    int max_step = 1, max_per_tile = 0;
     for (int d = dmin; d <= dmax; ++d) {
       while (gi < g.size() && g[gi] < d) ++gi;
       lb[(size_t)(d - dmin)] = (int)gi;
     }
+    int max_step = 1, max_step_y = 1;
     for (size_t k = 1; k < g.size(); ++k) max_step = std::max(max_step, g[k] - g[k - 1]);
-    int max_step_y = 1;
     for (size_t k = 1; k < dec->gy_host.size(); ++k)
       max_step_y = std::max(max_step_y, dec->gy_host[k] - dec->gy_host[k - 1]);
     dec->halo = (max_step + 1 + 3) & ~3;
     dec->lb_dmin = dmin;
     dec->lb_n = (int)lb.size();
-    // worst case over every gaze of the candidates one tile can receive from the three
-    // wrap states: grid points in [d, d + tile + halo) for d, d + W and d - W
-    auto lb_at = [&](long d) -> int {
-      if (d <= dmin) return 0;
-      if (d >= dmax) return (int)g.size();
-      return lb[(size_t)(d - dmin)];
-    };
-    const long win = kTileTexels + dec->halo;
-    for (long d = (long)dmin - source_width - win; d <= (long)dmax + source_width; ++d) {
-      int c = 0;
-      for (long k = -1; k <= 1; ++k)
-        c += lb_at(d + k * source_width + win) - lb_at(d + k * source_width);
-      max_per_tile = std::max(max_per_tile, c);
-    }
-    dec->stream_ok = dec->halo <= kMaxHalo && max_step_y < 256 && max_per_tile <= 64 * 6;
-    // the fovea: the longest run of reduced columns whose corners advance by one texel
-    {
-      int best_a = 0, best_b = 0, run_a = 0;
-      for (int i = 0; i <= target_width; ++i) {
-        const bool unit = i < target_width && g[(size_t)i + 1] - g[(size_t)i] == 1;
-        if (!unit) {
-          if (i - run_a > best_b - best_a) { best_a = run_a; best_b = i; }
-          run_a = i + 1;
-        }
-      }
-      dec->dense_begin = best_a;
-      dec->dense_end = best_b;
-      // worst-case candidates per tile once the fovea's columns are excluded
-      int worst = 0;
-      for (long d = (long)dmin - source_width - win; d <= (long)dmax + source_width; ++d) {
-        int c = 0;
-        for (long k = -1; k <= 1; ++k) {
-          const int ga = lb_at(d + k * source_width), gb = lb_at(d + k * source_width + win);
-          const int ia = std::max(ga - 1, 0), ib = std::max(std::min(gb - 1, target_width), ia);
-          c += std::max(std::min(ib, best_a) - ia, 0) + std::max(ib - std::max(ia, best_b), 0);
-        }
-        worst = std::max(worst, c);
-      }
-      dec->hybrid_passes = (best_b - best_a >= 256 && worst <= 64 * 6) ? (worst + 63) / 64 : 0;
-      if (dec->hybrid_passes == 0 && best_b - best_a >= 256 && worst <= 64 * 6) dec->hybrid_passes = 1;
-    }
+    // a tile's halo is at most 512 bytes (42 texels); box heights travel in 8 bits
+    dec->stream_ok = dec->halo <= 40 && max_step_y < 256;
     st = upload(dec->ctx, dec->lbx_dev, lb.data(), lb.size() * sizeof(int));
     if (st != F360_OK) return st;
     dec->lbx_host = std::move(lb);
@@ -1096,92 +854,69 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   sa.lb_dmin = dec->lb_dmin;
   sa.lb_n = dec->lb_n;
   sa.halo = dec->halo;
-  sa.dense_begin = sa.dense_end = 0;
-  sa.walk_blocks = 0;
   sa.ablate = ctx->opt_ablate;
   sa.reverse = ctx->opt_sample_reverse;
   const int variant = ctx->opt_sample_variant;
-  // the streaming variants' per-geometry tables (inverse grid, halo, candidate bounds) belong to
-  // the source size the grid was initialised for; any other size takes the walker
+  // the tile streamer's per-geometry tables (inverse grid, halo) belong to the source size the
+  // grid was initialised for; any other size takes the walker
   const bool can_stream = dec->stream_ok && (source_width % 4) == 0 &&
                           source_width == dec->sw && source_height == dec->sh &&
                           (size_t)source_width * source_height * 12 < ((size_t)1 << 32) &&
+                          (size_t)target_linesize * target_height < ((size_t)1 << 32) &&
                           ((uintptr_t)sat_dev % 16) == 0 && source_height <= 0xffff &&
                           target_height < 0xffff;
-  const int tile_blocks = ((source_width + kTileTexels - 1) / kTileTexels + 3) / 4;
-  const int run_blocks = (target_height + kStreamRows - 1) / kStreamRows;
   f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
-  int s4_passes = 0, s4_rot = 0, s4_th = 0;
-  if (variant == 4 && can_stream && dec->halo <= kS4MaxHalo) {
-    // candidates per tile for THIS gaze (the kernel enumerates exactly these windows)
-    const int ntiles = (source_width + kS4Tile - 1) / kS4Tile;
+  bool streamed = false;
+  if (variant == 2 && can_stream) {
+    // the kernel's candidate ranges per 128-texel tile for THIS gaze: the largest must fit two
+    // passes (128 pixels), the others together one (64)
+    const int ntiles = (source_width + kTsTile - 1) / kTsTile;
     const std::vector<int> &lb = dec->lbx_host;
     auto lb_at = [&](long d) {
       return lb[(size_t)std::min<long>(std::max<long>(d - dec->lb_dmin, 0), (long)lb.size() - 1)];
     };
-    int worst = 0;
-    for (int t = 0; t < ntiles; ++t) {
-      int total = 0;
-      for (int k = -1; k <= 1; ++k) {
-        const long lo_b = (long)t * kS4Tile + (long)k * source_width - cxp;
-        const long hi_b = lo_b + kS4Tile + (t == ntiles - 1 ? dec->halo : 0);
+    bool fits = true;
+    for (int t = 0; t < ntiles && fits; ++t) {
+      int largest = 0, total = 0;
+      for (int q = 0; q < kTsRanges; ++q) {
+        const int k = (q == 1 || q == 4) ? 1 : (q == 2 ? -1 : 0);
+        long lo_b = (long)t * kTsTile + (long)k * source_width - cxp, hi_b = lo_b + kTsTile;
+        if (q >= 3) {
+          lo_b = hi_b;
+          hi_b = lo_b + (t == ntiles - 1 ? dec->halo : 0);
+        }
         const int i_lo = std::max(lb_at(lo_b) - 1, 0);
         const int i_hi = std::max(std::min(lb_at(hi_b) - 1, target_width), i_lo);
+        largest = std::max(largest, i_hi - i_lo);
         total += i_hi - i_lo;
       }
-      worst = std::max(worst, total);
+      fits = largest <= kTsTile && total - largest <= 64;
     }
-    s4_passes = worst <= 64 * 4 ? 4 : (worst <= 64 * 6 ? 6 : 0);
-    // heavy tiles: those that overlap the fovea's unit-step columns (right corners
-    // cxp + gx[dense_begin + 1] .. cxp + gx[dense_end])
-    if (dec->dense_end > dec->dense_begin) {
-      auto floordiv = [](long v, long d) { return v >= 0 ? v / d : -((-v + d - 1) / d); };
-      const long t0 = floordiv((long)cxp + dec->gx_host[(size_t)dec->dense_begin + 1], kS4Tile);
-      const long t1 = floordiv((long)cxp + dec->gx_host[(size_t)dec->dense_end], kS4Tile);
-      s4_th = (int)std::min<long>(t1 - t0 + 1, ntiles);
-      s4_rot = (int)(((t0 % ntiles) + ntiles) % ntiles);
+    if (fits) {
+      const int rows = std::min(ctx->opt_stream_rows, kTsMaxRows);
+      const int nblocks = (target_height + rows - 1) / rows;
+      int istride = ctx->opt_stream_spread ? std::max(ntiles / 4, 1) : 1;
+      while (std::gcd(istride, ntiles) != 1) ++istride;
+      const dim3 sgrid((unsigned)((ntiles * nblocks + 3) / 4));
+#define F360_TS_LAUNCH(NS, G)                                                                  \
+  hipLaunchKernelGGL((sample_rect_stream_kernel<NS, G>), sgrid, dim3(256), 0, ctx->stream, sa, \
+                     rows, nblocks, 0, istride)
+      const int depth = ctx->opt_stream_depth;
+      if (ctx->opt_stream_groups) {
+        if (depth <= 2) F360_TS_LAUNCH(3, true);
+        else if (depth <= 3) F360_TS_LAUNCH(4, true);
+        else F360_TS_LAUNCH(6, true);
+      } else {
+        if (depth <= 2) F360_TS_LAUNCH(3, false);
+        else if (depth <= 3) F360_TS_LAUNCH(4, false);
+        else F360_TS_LAUNCH(6, false);
+      }
+#undef F360_TS_LAUNCH
+      streamed = true;
     }
   }
-  if (s4_passes > 0) {
-    const int hsplit = ctx->opt_stream_hsplit;
-    int rows = std::min(ctx->opt_stream_rows, kS4MaxRows);
-    rows = std::max(rows / hsplit, 1) * hsplit;
-    const int nblocks = (target_height + rows - 1) / rows;
-    const int ntiles = (source_width + kS4Tile - 1) / kS4Tile;
-    const int per_block = hsplit * s4_th + (ntiles - s4_th);
-    const int items = per_block * nblocks;
-    int istride = ctx->opt_stream_spread ? std::max(per_block / 4, 1) : 1;
-    while (std::gcd(istride, per_block) != 1) ++istride;
-    const dim3 sgrid((unsigned)((items + 3) / 4));
-    const int depth = ctx->opt_stream_depth;
-#define F360_S4_LAUNCH(P, D)                                                              \
-  hipLaunchKernelGGL((sample_rect_stream4_kernel<P, D>), sgrid, dim3(256), 0, ctx->stream, sa, \
-                     rows, nblocks, hsplit, s4_th, s4_rot, istride)
-    if (s4_passes == 4) {
-      if (depth == 2) F360_S4_LAUNCH(4, 2);
-      else if (depth == 4) F360_S4_LAUNCH(4, 4);
-      else F360_S4_LAUNCH(4, 6);
-    } else {
-      if (depth == 2) F360_S4_LAUNCH(6, 2);
-      else if (depth == 4) F360_S4_LAUNCH(6, 4);
-      else F360_S4_LAUNCH(6, 6);
-    }
-#undef F360_S4_LAUNCH
-  } else if (variant == 3 && can_stream && dec->hybrid_passes > 0) {
-    sa.dense_begin = dec->dense_begin;
-    sa.dense_end = dec->dense_end;
-    sa.walk_blocks =
-        ((dec->dense_end - dec->dense_begin + kWalkCols - 1) / kWalkCols + 3) / 4;
-    const dim3 hgrid(sa.walk_blocks + tile_blocks, run_blocks);
-    if (dec->hybrid_passes <= 2)
-      hipLaunchKernelGGL(sample_rect_stream_kernel<2>, hgrid, dim3(256), 0, ctx->stream, sa);
-    else if (dec->hybrid_passes <= 3)
-      hipLaunchKernelGGL(sample_rect_stream_kernel<3>, hgrid, dim3(256), 0, ctx->stream, sa);
-    else
-      hipLaunchKernelGGL(sample_rect_stream_kernel<6>, hgrid, dim3(256), 0, ctx->stream, sa);
-  } else if (variant == 2 && can_stream) {
-    hipLaunchKernelGGL(sample_rect_stream_kernel<6>, dim3(tile_blocks, run_blocks), dim3(256),
-                       0, ctx->stream, sa);
+  if (streamed) {
+    // launched above
   } else if (variant >= 1 && (size_t)source_width * source_height * 12 < ((size_t)1 << 32)) {
     const int rows = ctx->opt_walk_rows;
     const dim3 wgrid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),

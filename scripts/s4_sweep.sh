@@ -1,18 +1,16 @@
 #!/bin/bash
-# round 2: tile-streamer sampler (variant 4) against the walker, with ablations
+# round 2: the tile streamer (sample.variant=2) against the walker, with ablations
+# (debug.ablate 16: no stores, 32: no arithmetic and no stores)
 cd ${GRAFT_REPO_ROOT:-.}
-V="--opt sample.variant=4"
+V="--opt sample.variant=2"
 scripts/sweep.sh s4 \
   "--opt sample.variant=1" \
-  "$V --opt sample.srows=32 --opt sample.depth=2 --opt sample.spread=0" \
-  "$V --opt sample.srows=32 --opt sample.depth=2" \
-  "$V --opt sample.srows=32 --opt sample.depth=4" \
-  "$V --opt sample.srows=16 --opt sample.depth=2" \
-  "$V --opt sample.srows=64 --opt sample.depth=2" \
-  "$V --opt sample.srows=64 --opt sample.depth=4" \
-  "$V --opt sample.srows=32 --opt sample.depth=2 --opt sample.hsplit=2" \
-  "$V --opt sample.srows=64 --opt sample.depth=2 --opt sample.hsplit=4" \
-  "$V --opt sample.srows=32 --opt sample.depth=2 --opt debug.ablate=16" \
-  "$V --opt sample.srows=32 --opt sample.depth=2 --opt debug.ablate=32" \
-  "$V --opt sample.srows=32 --opt sample.depth=2 --opt debug.ablate=64" \
-  "$V --opt sample.srows=32 --opt sample.depth=2 --streams 3"
+  "$V" \
+  "$V --opt sample.srows=16" \
+  "$V --opt sample.srows=12" \
+  "$V --opt sample.depth=3" \
+  "$V --opt sample.spread=1" \
+  "$V --opt sample.groups=1" \
+  "$V --opt debug.ablate=16" \
+  "$V --opt debug.ablate=32" \
+  "$V --streams 3"

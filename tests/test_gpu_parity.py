@@ -23,10 +23,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
 GAZES = [(0.0, 0.0), (0.5, 0.5), (0.65, 0.75), (0.0, 1.0), (1.0, 1.0), (0.999, 0.5)]
 EXTRA_GAZES = [(-0.2, 1.3), (0.25, 0.1), (1.4, -0.3)]
-# every SAT sampler kernel: 0 per pixel, 1 column walker, 2 / 3 the round-1 row streamers,
-# 4 the tile streamer (falls back to the walker where it does not apply)
-SAMPLER_VARIANTS = (0, 1, 2, 3, 4)
-DEFAULT_SAMPLER = 4
+# every SAT sampler kernel: 0 per pixel, 1 column walker, 2 the tile streamer (the default; it
+# falls back to the walker where it does not apply)
+SAMPLER_VARIANTS = (0, 1, 2)
+DEFAULT_SAMPLER = 2
 
 
 def reduced(n):
@@ -592,32 +592,32 @@ def test_send_frame_loop_config5_8k(f360, gpu_ctx, oracle, tmp_path):
 
 @pytest.mark.parametrize("w,h", [(1920, 1080), (1028, 300)])
 def test_tile_streamer_options(f360, gpu_ctx, oracle, w, h):
-    """Variant 4 across its launch shapes: rows per wave (1 .. 64, incl. runs that do not
-    divide the height) and table rows in flight; gazes on the seam, outside the frame and in the
-    corners exercise the wrap states, the halo and the schedule's extra top rows."""
+    """The tile streamer across its launch shapes: rows per wave (1 .. 64, incl. runs that do not
+    divide the height), table rows in flight, tile order, 16-byte group stores; gazes on the
+    seam, outside the frame and in the corners exercise the wrap states, the halo and the
+    schedule's extra top rows."""
     rw, rh = reduced(w), reduced(h)
     frame = oracle.lcg_frame(w, h, 77)
     sat_h = oracle.sat_encode(frame, w, h, 4 * w)
     grid = oracle.satdec_grid(rw, rh, w, h)
     dec = f360.SATDecoder(gpu_ctx)
     dec.InitializeGrid(rw, rh, w, h)
-    old = {k: gpu_ctx.get_option(k)
-           for k in ("sample.variant", "sample.srows", "sample.depth", "sample.hsplit")}
-    gpu_ctx.set_option("sample.variant", 4)
+    keys = ("sample.variant", "sample.srows", "sample.depth", "sample.spread", "sample.groups")
+    old = {k: gpu_ctx.get_option(k) for k in keys}
+    gpu_ctx.set_option("sample.variant", 2)
     gazes = [(0.5, 0.5), (0.0, 0.0), (0.999, 0.5), (1.0, 1.0), (-0.2, 1.3), (0.031, 0.77), (1.4, -0.3)]
     wants = []
     for (cx, cy) in gazes:
         want = np.full((rh, 4 * rw + 8), 0xA5, dtype=np.uint8)
         oracle.satdec_sample_rect(want, rw, rh, 4 * rw + 8, sat_h, w, h, grid, cx, cy)
         wants.append(want)
-    for srows, depth, hsplit in [(1, 2, 1), (7, 4, 4), (16, 6, 2), (32, 4, 4), (64, 2, 1), (64, 6, 4),
-                                 (6, 2, 4), (32, 2, 2)]:
-        gpu_ctx.set_option("sample.srows", srows)
-        gpu_ctx.set_option("sample.depth", depth)
-        gpu_ctx.set_option("sample.hsplit", hsplit)
+    for srows, depth, spread, groups in [(1, 2, 0, 0), (7, 3, 1, 1), (16, 5, 0, 1), (32, 3, 1, 0),
+                                         (64, 2, 0, 1), (64, 5, 1, 0), (8, 2, 0, 1), (8, 2, 1, 0)]:
+        for k, v in zip(keys[1:], (srows, depth, spread, groups)):
+            gpu_ctx.set_option(k, v)
         for (cx, cy), want in zip(gazes, wants):
             got = run_sample_rect(f360, gpu_ctx, dec, sat_h, w, h, rw, rh, cx, cy, pad=8)
-            assert np.array_equal(got, want), (srows, depth, hsplit, cx, cy)
+            assert np.array_equal(got, want), (srows, depth, spread, groups, cx, cy)
     for k, v in old.items():
         gpu_ctx.set_option(k, v)
     dec.close()
