@@ -5,12 +5,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  A "step" is one pass of the hot path (SATEncoder::EncodeFrameGPU followed
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself: the
+parent -- which never touches a GPU -- runs the torch.distributed.run command above as a child
+process and exits with its code.  One process per GPU.  A "step" is one pass of the hot path (SATEncoder::EncodeFrameGPU followed
 by SATDecoder::SampleFrameRectGPU, through the C ABI of libf360.so) over this rank's batch of
 synthetic 7680x3840 RGB0 frames, which are resident in HBM before the timed region starts
 (BASELINE.json config "7680x3840 (8K) equirect, full SAT encode -> log-rectilinear decode
-pipeline, batch=64"; each rank owns `--batch` distinct frames, so scaling is weak and there is no
-data-path collective -- RCCL only reduces the final timing).  Frames go round-robin over
+pipeline, batch=64").  By default each rank owns `--batch` distinct frames (global frame index
+rank * batch + k), so scaling is WEAK and that is what `value` reports; `--global-batch G` is
+BASELINE config 4 read literally -- ONE batch of G frames cut into contiguous blocks
+(sharding.shard_range: 64 -> 8 per GPU at N = 8), "scaling": "strong".  Either way there is no
+data-path collective: RCCL only reduces the final timing.  `--dry-run` prints the per-rank frame
+ranges and the launch command without touching a GPU.  Frames go round-robin over
 `--streams` contexts (one in-order stream each, like one connection each in the reference's
 server); every `--profile-every`-th frame runs alone on the GPU with HIP event pairs around each
 of its kernels -- that is where `roofline` comes from.  The metric is input Mpixels/s over
@@ -48,34 +54,79 @@ def algorithmic_bytes(w, h, rw, rh):
     return enc, smp
 
 
-def cpu_baseline(w, h, rw, rh, seconds_budget=20.0):
-    """The oracle's SAT encode + sample (kind "port") on the host cores, bounded sample."""
-    import concurrent.futures as cf
+def cpu_baseline(w, h, rw, rh, per_thread=6):
+    """The oracle's SAT encode + sample (kind "port") on the host cores, COMPUTE ONLY: every
+    thread synthesises its frames first, all threads meet at a barrier, and the clock runs from
+    there to the last thread's end.  Bounded sample: per_thread frames on each of <= 16 threads."""
+    import threading
+    import numpy as np
     import oracle_binding as ob
     ob.lib()
-    # one frame on one thread to size the sample
-    _, t1 = ob.pipeline_encode_sample(1, w, h, rw, rh, 1)
     cores = max(1, min(16, os.cpu_count() or 1))
-    per_thread = max(1, int(seconds_budget / max(t1, 1e-3) / 1.5))
-    per_thread = min(per_thread, 8)
+    # one thread alone, two frames
+    solo = np.stack([ob.lcg_frame(w, h, 1).reshape(h, 4 * w), ob.lcg_frame(w, h, 2).reshape(h, 4 * w)])
+    _, t_solo = ob.pipeline_compute(solo, 0, w, h, rw, rh)
+    single = 2 * w * h / 1e6 / t_solo
+    del solo
+    gate = threading.Barrier(cores + 1)
+    ends, busy = [0.0] * cores, [0.0] * cores
+
+    def worker(i):
+        mine = np.empty((per_thread, h, 4 * w), dtype=np.uint8)
+        for k in range(per_thread):  # ctypes releases the GIL during the fill
+            mine[k] = ob.lcg_frame(w, h, 1000 + 100 * i + k).reshape(h, 4 * w)
+        gate.wait()
+        _, busy[i] = ob.pipeline_compute(mine, i * per_thread, w, h, rw, rh)
+        ends[i] = time.perf_counter()
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+    for t in threads:
+        t.start()
+    gate.wait()
     t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL during the call
-        futs = [ex.submit(ob.pipeline_encode_sample, per_thread, w, h, rw, rh, 1000 + 100 * i)
-                for i in range(cores)]
-        res = [f.result() for f in futs]
-    wall = time.perf_counter() - t0
+    for t in threads:
+        t.join()
+    wall = max(ends) - t0
     frames = per_thread * cores
-    busy = sum(r[1] for r in res)
     return {
-        "value": round(frames * w * h / 1e6 / wall, 2),
+        "value": round(frames * w * h / 1e6 / wall, 1),
         "unit": "Mpixels/s",
         "cores": cores,
         "kind": "port",
-        "sample": (f"{frames} frames {w}x{h} ({per_thread} per thread x {cores} threads), oracle "
-                   f"f360o_sat_encode + f360o_satdec_sample_rect, wall {wall:.1f}s incl. LCG frame "
-                   f"synthesis; 1 thread: {w * h / 1e6 / t1:.1f} Mpixels/s; timed compute "
-                   f"{busy:.1f} core-s"),
+        "single_thread_value": round(single, 1),
+        "sample": (f"{frames} frames {w}x{h} ({per_thread} per thread x {cores} threads) synthesised "
+                   f"before the clock starts; oracle f360o_sat_encode + f360o_satdec_sample_rect, "
+                   f"compute-only wall {wall:.2f}s ({sum(busy):.1f} core-s); one thread alone: "
+                   f"{single:.1f} Mpixels/s"),
     }
+
+
+def launch_plan(gpus, batch, global_batch):
+    """Global frame indices each rank owns: contiguous blocks of ONE batch (--global-batch,
+    sharding.shard_range) or `batch` frames per rank (weak scaling, the default)."""
+    from importlib import import_module
+    sharding = import_module("foveated-360-video_amd.sharding")
+    if global_batch:
+        return [sharding.shard_range(global_batch, gpus, r) for r in range(gpus)]
+    return [range(r * batch, (r + 1) * batch) for r in range(gpus)]
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: run N fresh ranks under torch.distributed.run as a child
+    process.  The parent has not imported torch or made any GPU call, and it never execs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + argv
+    if args.dry_run:
+        return cmd
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -85,7 +136,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=3840)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="ONE batch of this many frames sharded over the ranks in contiguous "
+                         "blocks (BASELINE config 4: 64 -> 8 per GPU at N = 8); overrides --batch")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the launch command and the per-rank frame ranges; no GPU call")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (in-order streams) per GPU; frames go round-robin over them "
                          "(3 gives ~15%% more throughput; 1 keeps every kernel launch comparable with "
@@ -108,20 +164,37 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (invalid as a measurement)")
     args = ap.parse_args()
+    if args.gpus < 1 or args.batch < 1 or args.global_batch < 0:
+        ap.error("--gpus and --batch must be >= 1, --global-batch >= 0")
+    if args.global_batch and args.global_batch < args.gpus:
+        ap.error("--global-batch smaller than --gpus leaves ranks without a frame")
+
+    launched = "WORLD_SIZE" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    plan = launch_plan(args.gpus, args.batch, args.global_batch)
+    if args.dry_run:
+        argv = [a for a in sys.argv[1:] if a != "--dry-run"]
+        print(json.dumps({
+            "gpus": args.gpus, "scaling": "strong" if args.global_batch else "weak",
+            "frames_total": sum(len(r) for r in plan),
+            "ranks": [{"rank": r, "frames": [rg.start, rg.stop]} for r, rg in enumerate(plan)],
+            "launch": (self_launch(args, argv) if args.gpus > 1 and not launched
+                       else [sys.executable, os.path.abspath(__file__)] + argv)}))
+        return
+    if launched and world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count "
+                  f"and --gpus must agree", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
-                  f"torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no HIP device visible; this benchmark has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -138,20 +211,26 @@ def main():
     import f360_amd as f360  # after torch: share torch's HIP runtime
     w, h = args.width, args.height
     rw, rh = reduced(w), reduced(h)
-    B = args.batch
+    mine = plan[rank]  # global indices of this rank's frames
+    B = len(mine)
 
-    # ---- synthetic, device-resident inputs: B distinct frames per rank -------------------
+    # ---- synthetic, device-resident inputs: frame g is the same bytes whichever rank owns it --
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
     yuv = args.source == "yuv420p"
     if yuv:
-        planes_y = torch.randint(0, 256, (B, h, w), dtype=torch.uint8, device=dev, generator=gen)
-        planes_u = torch.randint(0, 256, (B, h // 2, w // 2), dtype=torch.uint8, device=dev,
-                                 generator=gen)
-        planes_v = torch.randint(0, 256, (B, h // 2, w // 2), dtype=torch.uint8, device=dev,
-                                 generator=gen)
+        planes_y = torch.empty((B, h, w), dtype=torch.uint8, device=dev)
+        planes_u = torch.empty((B, h // 2, w // 2), dtype=torch.uint8, device=dev)
+        planes_v = torch.empty((B, h // 2, w // 2), dtype=torch.uint8, device=dev)
     else:
-        frames = torch.randint(0, 256, (B, h, w * 4), dtype=torch.uint8, device=dev, generator=gen)
+        frames = torch.empty((B, h, w * 4), dtype=torch.uint8, device=dev)
+    for k, g in enumerate(mine):
+        gen.manual_seed(1234 + g)
+        if yuv:
+            planes_y[k].random_(0, 256, generator=gen)
+            planes_u[k].random_(0, 256, generator=gen)
+            planes_v[k].random_(0, 256, generator=gen)
+        else:
+            frames[k].random_(0, 256, generator=gen)
     nstreams = max(1, args.streams)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
     ctxs = [f360.Context(local_rank, stream=s.cuda_stream) for s in streams]
@@ -165,7 +244,7 @@ def main():
         d.InitializeGrid(rw, rh, w, h)
     sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev) for _ in ctxs]
     reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
-    gazes = [lissajous(k) for k in range(B)]
+    gazes = [lissajous(g) for g in mine]
     if yuv:
         yuv_ptr = [(planes_y[k].data_ptr(), planes_u[k].data_ptr(), planes_v[k].data_ptr())
                    for k in range(B)]
@@ -257,12 +336,18 @@ def main():
             avg_s = kernels[dom]["avg_us"] * 1e-6
             dom_bytes = frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes
             achieved = dom_bytes / avg_s / 1e9
+            # PMC traffic is a measurement of a particular build: profiles/pmc_traffic.json carries
+            # the hash of the kernel sources it was taken on and is ignored (null) for any other
             traffic = None
             tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath) and not args.fused:
                 try:
+                    sys.path.insert(0, os.path.join(REPO, "scripts"))
+                    from pmc_traffic import csrc_hash
                     with open(tpath) as f:
-                        traffic = json.load(f).get(dom, {}).get(f"{w}x{h}" + (":yuv420p" if yuv else ""))
+                        doc = json.load(f)
+                    if doc.get("csrc_sha") == csrc_hash():
+                        traffic = doc.get(dom, {}).get(f"{w}x{h}" + (":yuv420p" if yuv else ""))
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom + (" (emit mode)" if args.fused else ""),
@@ -282,16 +367,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic" if not args.share_device else "synthetic (REHEARSAL: ranks share GPU 0)",
             "config": {"workload": f"{w}x{h} {'planar YUV 4:2:0' if yuv else 'RGB0'} equirect frames, "
                                    f"{'fused SAT encode + ' if args.fused else 'SAT encode -> '}"
-                                   f"log-rectilinear SAT sample to {rw}x{rh}, batch {B} frames per "
-                                   f"GPU per step, Lissajous gaze, inputs resident in HBM",
+                                   f"log-rectilinear SAT sample to {rw}x{rh}, "
+                                   + (f"ONE batch of {args.global_batch} frames per step sharded over "
+                                      f"the GPUs in contiguous blocks" if args.global_batch else
+                                      f"batch {B} frames per GPU per step")
+                                   + ", Lissajous gaze, inputs resident in HBM",
                        "source": args.source, "fused": bool(args.fused),
                        "frame": [w, h], "reduced": [rw, rh], "batch_per_gpu": B,
+                       "global_batch": args.global_batch or None,
                        "streams_per_gpu": nstreams, "parallelism": f"frames sharded x{world}"},
             "roofline": roof,
             "path_hbm_frac": round(path_bytes * (total_px / (w * h)) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),

@@ -88,7 +88,7 @@ extern "C" int f360_yuv420p_to_rgb0(f360_ctx *ctx, uint8_t *dst_dev, int dst_lin
   F360_REQUIRE(dst_linesize >= 4 * width && y_linesize >= width &&
                    u_linesize >= (width + 1) / 2 && v_linesize >= (width + 1) / 2,
                "f360_yuv420p_to_rgb0: linesize too small");
-  F360_HIP_TRY(hipSetDevice(ctx->device));
+  F360_BIND_DEVICE(ctx);
   YuvConsts k;
   f360::build_yuv2rgb_consts(k);
   const YuvPlanes p{y_dev, u_dev, v_dev, y_linesize, u_linesize, v_linesize};

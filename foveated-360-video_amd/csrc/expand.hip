@@ -117,7 +117,7 @@ extern "C" int f360_expand_rect(f360_ctx *ctx, uint8_t *dst_dev, int dst_w, int 
   int st = expand_common(ctx, a, dst_dev, dst_w, dst_h, dst_linesize, src_dev, src_w, src_h,
                          src_linesize, center_x, center_y, "f360_expand_rect");
   if (st != F360_OK) return st;
-  F360_HIP_TRY(hipSetDevice(ctx->device));
+  F360_BIND_DEVICE(ctx);
   if (!(ctx->ex_kind == 0 && ctx->ex_w == src_w && ctx->ex_h == src_h && ctx->ex_tw == dst_w &&
         ctx->ex_th == dst_h)) {
     std::vector<int32_t> dx, dy;
@@ -155,7 +155,7 @@ extern "C" int f360_expand_logpolar(f360_ctx *ctx, uint8_t *dst_dev, int dst_w, 
   if (st != F360_OK) return st;
   F360_REQUIRE((uint64_t)src_w * (uint64_t)src_h < 0xffffffffull,
                "f360_expand_logpolar: source too large");
-  F360_HIP_TRY(hipSetDevice(ctx->device));
+  F360_BIND_DEVICE(ctx);
   const size_t n_keys = (size_t)dst_w * dst_h;
   const size_t table_bytes = (size_t)src_h * 2 * sizeof(double) + (size_t)src_w * sizeof(float);
   if (!(ctx->ex_kind == 1 && ctx->ex_w == src_w && ctx->ex_h == src_h && ctx->ex_tw == dst_w &&

@@ -33,6 +33,34 @@ void set_error(const char *fmt, ...);
     }                                    \
   } while (0)
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the guard and puts
+// the previous one back afterwards: every C-ABI entry that allocates, copies or launches binds
+// its context's device this way, so one thread may hold contexts on several GPUs.
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    if (prev_ != device) {
+      status_ = hipSetDevice(device);
+      changed_ = status_ == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+  hipError_t status() const { return status_; }
+
+ private:
+  int prev_ = -1;
+  bool changed_ = false;
+  hipError_t status_ = hipSuccess;
+};
+#define F360_BIND_DEVICE(ctx_expr)                         \
+  ::f360::DeviceGuard _f360_guard((ctx_expr)->device);     \
+  F360_HIP_TRY(_f360_guard.status())
+
 // A device allocation owned by an engine object.
 struct DevBuf {
   void *p = nullptr;

@@ -76,7 +76,8 @@ static int ctx_create_common(int device, void *stream, bool borrow,
   if (st != F360_OK) return st;
   F360_REQUIRE(device >= 0 && device < n, "f360_ctx_create: device %d of %d",
                device, n);
-  F360_HIP_TRY(hipSetDevice(device));
+  f360::DeviceGuard guard(device);  // the caller's current device is left as it was
+  F360_HIP_TRY(guard.status());
   f360_ctx *ctx = new f360_ctx();
   ctx->device = device;
   if (borrow) {
@@ -105,7 +106,7 @@ int f360_ctx_create_on_stream(int device, void *hip_stream, f360_ctx **out) {
 
 int f360_ctx_destroy(f360_ctx *ctx) {
   if (!ctx) return F360_OK;
-  (void)hipSetDevice(ctx->device);
+  f360::DeviceGuard guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->enc.ws.release();
   ctx->ex_tables.release();
@@ -135,6 +136,7 @@ int f360_ctx_stream(const f360_ctx *ctx, void **hip_stream) {
 
 int f360_sync(f360_ctx *ctx) {
   F360_REQUIRE(ctx, "f360_sync: null context");
+  F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return F360_OK;
 }
@@ -142,7 +144,7 @@ int f360_sync(f360_ctx *ctx) {
 int f360_malloc(f360_ctx *ctx, size_t bytes, void **dptr) {
   F360_REQUIRE(ctx && dptr, "f360_malloc: null argument");
   *dptr = nullptr;
-  F360_HIP_TRY(hipSetDevice(ctx->device));
+  F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
   return F360_OK;
 }
@@ -150,6 +152,7 @@ int f360_malloc(f360_ctx *ctx, size_t bytes, void **dptr) {
 int f360_free(f360_ctx *ctx, void *dptr) {
   F360_REQUIRE(ctx, "f360_free: null context");
   if (!dptr) return F360_OK;
+  F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
   F360_HIP_TRY(hipFree(dptr));
   return F360_OK;
@@ -157,6 +160,7 @@ int f360_free(f360_ctx *ctx, void *dptr) {
 
 int f360_memset(f360_ctx *ctx, void *dptr, int value, size_t bytes) {
   F360_REQUIRE(ctx && dptr, "f360_memset: null argument");
+  F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipMemsetAsync(dptr, value, bytes, ctx->stream));
   return F360_OK;
 }
@@ -164,6 +168,7 @@ int f360_memset(f360_ctx *ctx, void *dptr, int value, size_t bytes) {
 int f360_memcpy_h2d_async(f360_ctx *ctx, void *dst_dev, const void *src_host,
                           size_t bytes) {
   F360_REQUIRE(ctx && dst_dev && src_host, "f360_memcpy_h2d: null argument");
+  F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice,
                               ctx->stream));
   return F360_OK;
@@ -172,6 +177,7 @@ int f360_memcpy_h2d_async(f360_ctx *ctx, void *dst_dev, const void *src_host,
 int f360_memcpy_d2h_async(f360_ctx *ctx, void *dst_host, const void *src_dev,
                           size_t bytes) {
   F360_REQUIRE(ctx && dst_host && src_dev, "f360_memcpy_d2h: null argument");
+  F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost,
                               ctx->stream));
   return F360_OK;
@@ -205,6 +211,7 @@ int f360_host_free_pinned(void *hptr) {
 
 int f360_event_create(f360_ctx *ctx, f360_event **ev) {
   F360_REQUIRE(ctx && ev, "f360_event_create: null argument");
+  F360_BIND_DEVICE(ctx);
   f360_event *e = new f360_event();
   hipError_t r = hipEventCreate(&e->ev);
   if (r != hipSuccess) {
@@ -225,6 +232,7 @@ int f360_event_destroy(f360_event *ev) {
 
 int f360_event_record(f360_ctx *ctx, f360_event *ev) {
   F360_REQUIRE(ctx && ev, "f360_event_record: null argument");
+  F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipEventRecord(ev->ev, ctx->stream));
   return F360_OK;
 }
@@ -317,6 +325,7 @@ const char *f360_kernel_name(int kernel_id) {
 
 int f360_ctx_profile_arm(f360_ctx *ctx, int calls) {
   F360_REQUIRE(ctx && calls >= 0, "f360_ctx_profile_arm: bad argument");
+  F360_BIND_DEVICE(ctx);
   ctx->prof_armed = calls;
   return F360_OK;
 }
@@ -340,6 +349,7 @@ int f360_ctx_profile_read(f360_ctx *ctx, int kernel_id, double *total_ms,
   F360_REQUIRE(ctx && total_ms && launches && kernel_id >= 0 &&
                    kernel_id < f360::kKernelCount,
                "f360_ctx_profile_read: bad argument");
+  F360_BIND_DEVICE(ctx);
   int st = profile_collect(ctx);
   if (st != F360_OK) return st;
   *total_ms = ctx->prof_ms[kernel_id];
@@ -349,6 +359,7 @@ int f360_ctx_profile_read(f360_ctx *ctx, int kernel_id, double *total_ms,
 
 int f360_ctx_profile_reset(f360_ctx *ctx) {
   F360_REQUIRE(ctx, "f360_ctx_profile_reset: null context");
+  F360_BIND_DEVICE(ctx);
   int st = profile_collect(ctx);
   if (st != F360_OK) return st;
   for (int k = 0; k < f360::kKernelCount; ++k) {

@@ -344,7 +344,7 @@ int f360_is_initialize_grid(f360_image_sampler *is, int target_width,
   if (is->gw == target_width && is->gh == target_height && is->sw == source_width &&
       is->sh == source_height && is->gx_dev.p)
     return F360_OK;
-  F360_HIP_TRY(hipSetDevice(is->ctx->device));
+  F360_BIND_DEVICE(is->ctx);
   f360::build_is_grid_axis(is->gx_host, target_width, source_width);
   f360::build_is_grid_axis(is->gy_host, target_height, source_height);
   int st = upload(is->ctx, is->gx_dev, is->gx_host.data(),
@@ -371,7 +371,7 @@ int f360_is_initialize_logpolar_grid(f360_image_sampler *is, int target_width,
     is->lsh = source_height;
     return F360_OK;
   }
-  F360_HIP_TRY(hipSetDevice(is->ctx->device));
+  F360_BIND_DEVICE(is->ctx);
   f360::build_logpolar_axes(is->lrad_host, is->lcos_host, is->lsin_host,
                             target_width, target_height);
   int st = upload(is->ctx, is->lrad_dev, is->lrad_host.data(),
@@ -441,6 +441,7 @@ int f360_is_sample_rect(f360_image_sampler *is, uint8_t *target_dev,
                         int source_width, int source_height,
                         int source_linesize, float center_x, float center_y) {
   F360_REQUIRE(is, "f360_is_sample_rect: null sampler");
+  F360_BIND_DEVICE(is->ctx);
   F360_REQUIRE(target_dev && source_dev, "f360_is_sample_rect: null buffer");
   if (!is->gx_dev.p) {  // the reference never auto-initialises (image_sampler.cc:261)
     f360::set_error("f360_is_sample_rect: InitializeGrid has not been called");
@@ -474,6 +475,7 @@ int f360_is_sample_logpolar(f360_image_sampler *is, uint8_t *target_dev,
                             int source_linesize, float center_x,
                             float center_y) {
   F360_REQUIRE(is, "f360_is_sample_logpolar: null sampler");
+  F360_BIND_DEVICE(is->ctx);
   F360_REQUIRE(target_dev && source_dev, "f360_is_sample_logpolar: null buffer");
   if (!is->lrad_dev.p) {
     f360::set_error(
@@ -509,6 +511,7 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
                                  int source_linesize, float center_x,
                                  float center_y) {
   (void)target_linesize;
+  F360_BIND_DEVICE(is->ctx);
   (void)source_linesize;
   F360_REQUIRE(is, "f360_is_interpolate_logpolar: null sampler");
   F360_REQUIRE(target_dev && source_dev, "f360_is_interpolate_logpolar: null buffer");
@@ -520,7 +523,6 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
   F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),
                "f360_is_interpolate_logpolar: gaze centre out of range");
   if (is->iw != source_width || is->ih != source_height || !is->irad_dev.p) {
-    F360_HIP_TRY(hipSetDevice(is->ctx->device));
     std::vector<float> rad;
     std::vector<double> cs, sn;
     f360::build_logpolar_inverse_axes(rad, cs, sn, source_width, source_height);
@@ -540,7 +542,6 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
   if (is->ctx->opt_lp_table && table_bytes <= ((size_t)1 << 30)) {
     if (is->lpt_w != target_width || is->lpt_h != target_height || is->lpt_sw != source_width ||
         is->lpt_sh != source_height || !is->lpt_dev.p) {
-      F360_HIP_TRY(hipSetDevice(is->ctx->device));
       F360_HIP_TRY(hipStreamSynchronize(is->ctx->stream));  // earlier calls may read the old one
       int st = is->lpt_dev.reserve(table_bytes);
       if (st != F360_OK) return st;
@@ -576,7 +577,8 @@ int f360_is_logpolar_gaussian_blur(f360_image_sampler *is, uint8_t *target_dev,
                                    int target_width, int target_height,
                                    int target_linesize,
                                    const uint8_t *source_dev) {
-  (void)target_linesize;  // kernel indexes 4-byte texels with a row stride of width
+  (void)target_linesize;
+  F360_BIND_DEVICE(is->ctx);  // kernel indexes 4-byte texels with a row stride of width
   F360_REQUIRE(is, "f360_is_logpolar_gaussian_blur: null sampler");
   F360_REQUIRE(target_dev && source_dev, "f360_is_logpolar_gaussian_blur: null buffer");
   F360_REQUIRE(target_width >= 1 && target_height >= 1,

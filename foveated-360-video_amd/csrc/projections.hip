@@ -98,6 +98,7 @@ extern "C" int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_widt
   (void)target_linesize;  // 4-byte texels, tightly packed rows, as in the kernel
   (void)source_linesize;
   F360_REQUIRE(ctx, "f360_gnomonic: null context");
+  F360_BIND_DEVICE(ctx);
   F360_REQUIRE(target_dev && source_dev, "f360_gnomonic: null buffer");
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 1 &&
                    source_height >= 1,
@@ -116,7 +117,6 @@ extern "C" int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_widt
   const size_t table_bytes = (size_t)target_width * target_height * 5 * sizeof(float);
   if (ctx->opt_gnomonic_table && table_bytes <= ((size_t)1 << 30)) {
     if (ctx->gn_w != target_width || ctx->gn_h != target_height || !ctx->gn_table.p) {
-      F360_HIP_TRY(hipSetDevice(ctx->device));
       F360_HIP_TRY(hipStreamSynchronize(ctx->stream));  // earlier calls may read the old table
       int st = ctx->gn_table.reserve(table_bytes);
       if (st != F360_OK) return st;

@@ -751,7 +751,7 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
   if (dec->gw == target_width && dec->gh == target_height &&
       dec->sw == source_width && dec->sh == source_height && dec->gx_dev.p)
     return F360_OK;
-  F360_HIP_TRY(hipSetDevice(dec->ctx->device));
+  F360_BIND_DEVICE(dec->ctx);
   f360::build_satdec_grid_axis(dec->gx_host, target_width, source_width);
   f360::build_satdec_grid_axis(dec->gy_host, target_height, source_height);
   int st = upload(dec->ctx, dec->gx_dev, dec->gx_host.data(),
@@ -793,6 +793,7 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
 
 int f360_satdec_export_grid(f360_sat_decoder *dec, int16_t *grid_host) {
   F360_REQUIRE(dec && grid_host, "f360_satdec_export_grid: null argument");
+  F360_BIND_DEVICE(dec->ctx);
   if (!dec->gx_dev.p) {
     f360::set_error("f360_satdec_export_grid: grid not initialised");
     return F360_ERR_NOT_INITIALIZED;
@@ -819,6 +820,7 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
                             int source_width, int source_height, float center_x,
                             float center_y) {
   F360_REQUIRE(dec, "f360_satdec_sample_rect: null decoder");
+  F360_BIND_DEVICE(dec->ctx);
   F360_REQUIRE(target_dev && sat_dev, "f360_satdec_sample_rect: null buffer");
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width,
@@ -939,6 +941,7 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
                                   int source_width, int source_height,
                                   const float *centers_xy) {
   F360_REQUIRE(dec, "f360_satdec_sample_rect_batch: null decoder");
+  F360_BIND_DEVICE(dec->ctx);
   F360_REQUIRE(targets_dev && sat_dev && centers_xy,
                "f360_satdec_sample_rect_batch: null buffer");
   F360_REQUIRE(count >= 1 && count <= kMaxBatch,
@@ -1009,7 +1012,7 @@ int foveate_rect_impl(f360_sat_decoder *dec, uint8_t *target_dev, int target_wid
   F360_REQUIRE(dec->gw == target_width && dec->gh == target_height,
                "f360_satdec_foveate_rect: grid was initialised for %dx%d", dec->gw, dec->gh);
   f360_ctx *ctx = dec->ctx;
-  F360_HIP_TRY(hipSetDevice(ctx->device));
+  F360_BIND_DEVICE(ctx);
   // compact corner array: at most two distinct corners per reduced column / row
   const int cap_x = std::min(2 * target_width + 2, source_width);
   const int cap_y = std::min(2 * target_height + 2, source_height);
@@ -1097,6 +1100,7 @@ int f360_satdec_decode(f360_sat_decoder *dec, uint8_t *target_dev,
                        int target_linesize, const uint32_t *sat_dev, int width,
                        int height) {
   F360_REQUIRE(dec, "f360_satdec_decode: null decoder");
+  F360_BIND_DEVICE(dec->ctx);
   F360_REQUIRE(target_dev && sat_dev, "f360_satdec_decode: null buffer");
   F360_REQUIRE(width >= 1 && height >= 1 && target_linesize / width >= 3,
                "f360_satdec_decode: bad geometry");
@@ -1144,7 +1148,7 @@ int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   // largest |offset| any pixel can have after the single +-W wrap
   const int need_dx = imax(iabs(0 - cxp), iabs(target_width - 1 - cxp)) + 1;
   const int need_dy = imax(iabs(0 - cyp), iabs(target_height - 1 - cyp)) + 1;
-  F360_HIP_TRY(hipSetDevice(dec->ctx->device));
+  F360_BIND_DEVICE(dec->ctx);
   int st = ensure_interp_tables(dec, target_width, target_height, source_width,
                                 source_height, need_dx, need_dy);
   if (st != F360_OK) return st;

@@ -782,7 +782,7 @@ extern "C" int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height) {
   F360_REQUIRE(ctx, "f360_sat_encode_prepare: null context");
   F360_REQUIRE(width >= 1 && height >= 1, "f360_sat_encode_prepare: bad size %dx%d",
                width, height);
-  F360_HIP_TRY(hipSetDevice(ctx->device));
+  F360_BIND_DEVICE(ctx);
   return ensure_plan(ctx, width, height);
 }
 
@@ -791,6 +791,7 @@ namespace f360 {
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv) {
   F360_REQUIRE(ctx, "f360_sat_encode: null context");
+  F360_BIND_DEVICE(ctx);
   F360_REQUIRE((sat_dev || emit) && (src_dev || yuv), "f360_sat_encode: null buffer");
   F360_REQUIRE(width >= 1 && height >= 1, "f360_sat_encode: bad size %dx%d", width,
                height);

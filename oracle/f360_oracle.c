@@ -589,3 +589,34 @@ uint64_t f360o_pipeline_encode_sample(int frames, int src_w, int src_h,
   free(grid);
   return digest;
 }
+
+/* The same hot path over frames the caller has already synthesised (`frames` holds `nframes`
+ * RGB0 frames back to back, frame k sampled at the Lissajous gaze of index first_index + k):
+ * bench.py's cpu_baseline times THIS, so the figure is compute only.  The scratch buffers are
+ * allocated and touched before the clock starts. */
+uint64_t f360o_pipeline_compute(const uint8_t *frames, int nframes, int first_index, int src_w,
+                                int src_h, int out_w, int out_h, double *seconds_out) {
+  const size_t fbytes = (size_t)4 * src_w * src_h;
+  const size_t obytes = (size_t)4 * out_w * out_h;
+  uint32_t *sat = (uint32_t *)calloc((size_t)3 * src_w * src_h, sizeof(uint32_t));
+  uint8_t *red = (uint8_t *)calloc(obytes, 1);
+  int16_t *grid =
+      (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)(out_w + 1) * (out_h + 1));
+  f360o_satdec_grid(grid, out_w, out_h, src_w, src_h);
+  uint64_t digest = 0xcbf29ce484222325ull;
+  const double t0 = now_s();
+  for (int k = 0; k < nframes; ++k) {
+    const int g = first_index + k;
+    float gx = (float)(0.5 + 0.45 * sin(2.0 * M_PI * (double)g / 97.0));
+    float gy = (float)(0.5 + 0.35 * sin(2.0 * M_PI * (double)g / 61.0));
+    f360o_sat_encode(sat, frames + (size_t)k * fbytes, src_w, src_h, 4 * src_w);
+    f360o_satdec_sample_rect(red, out_w, out_h, 4 * out_w, sat, src_w, src_h, grid, gx, gy);
+    digest ^= f360o_fnv1a64(red, obytes);
+    digest *= 0x100000001b3ull;
+  }
+  if (seconds_out) *seconds_out = now_s() - t0;
+  free(sat);
+  free(red);
+  free(grid);
+  return digest;
+}

@@ -130,6 +130,9 @@ void f360o_expand_logpolar(uint8_t *dst, int dst_w, int dst_h, int dst_linesize,
 uint64_t f360o_pipeline_encode_sample(int frames, int src_w, int src_h,
                                       int out_w, int out_h, uint32_t seed0,
                                       double *seconds_out);
+/* the same over frames synthesised by the caller: compute only (bench.py's cpu_baseline) */
+uint64_t f360o_pipeline_compute(const uint8_t *frames, int nframes, int first_index, int src_w,
+                                int src_h, int out_w, int out_h, double *seconds_out);
 
 #ifdef __cplusplus
 }

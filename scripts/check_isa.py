@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Build-time guard for the hand-kept memory-pipeline tricks.
+
+The table writer, the reducer and the tile-streamer sampler depend on things the compiler's
+model does not cover: stores and LDS exchanges issued from inline asm, load waits that count the
+YOUNGER loads instead of draining (`s_waitcnt vmcnt(N)`, N > 0), non-temporal stores.  A ROCm
+bump that re-serialises one of their inner loops would still pass every parity test -- and cost
+20-40 %.  This script disassembles the gfx950 code objects inside libf360.so and fails when
+
+  * a loop of sat_write_kernel that stores table rows contains `s_waitcnt vmcnt(0)`, or
+    sat_reduce_kernel has no row-batch loop left that waits with counted vmcnt only;
+  * a table store of sat_write_kernel lost its `nt` bit;
+  * the row loop of sample_rect_stream_kernel lost its LDS-direct loads, waits with vmcnt(0), or
+    no longer waits with a counted vmcnt at all.
+
+    python scripts/check_isa.py [path/to/libf360.so]        (exit 0 = all rules hold)
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def code_objects(lib):
+    tmp = tempfile.mkdtemp(prefix="f360_isa_")
+    shutil.copy(lib, os.path.join(tmp, "lib.so"))
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=tmp, capture_output=True, check=True)
+    return tmp, [os.path.join(tmp, f) for f in sorted(os.listdir(tmp)) if f.endswith("gfx950")]
+
+
+def functions(path):
+    """{name: [(addr, text, branch_target_or_None)]}"""
+    out = subprocess.run([OBJDUMP, "-d", path], capture_output=True, text=True, check=True).stdout
+    funcs, cur, base = {}, None, 0
+    for line in out.splitlines():
+        m = re.match(r"^([0-9a-f]{16}) <(.+)>:$", line)
+        if m:
+            base, cur = int(m.group(1), 16), m.group(2)
+            funcs[cur] = []
+            continue
+        m = re.match(r"^\t(.+?)\s+// ([0-9A-F]{12}):", line)
+        if not (m and cur):
+            continue
+        text, addr = m.group(1).strip(), int(m.group(2), 16)
+        tgt = None
+        if text.startswith(("s_cbranch", "s_branch")):
+            t = re.search(r"<.+\+0x([0-9a-f]+)>\s*$", line)
+            tgt = base + int(t.group(1), 16) if t else (base if line.rstrip().endswith(">") else None)
+        funcs[cur].append((addr, text, tgt))
+    return funcs
+
+
+def loops(ins):
+    """Instruction slices of every INNERMOST loop (a backward branch and everything up to its
+    target, with no other loop inside)."""
+    index = {a: i for i, (a, _, _) in enumerate(ins)}
+    spans = [(index[tgt], i) for i, (a, _, tgt) in enumerate(ins)
+             if tgt is not None and tgt <= a and tgt in index]
+    inner = [(lo, hi) for lo, hi in spans
+             if not any((l2, h2) != (lo, hi) and lo <= l2 and h2 <= hi for l2, h2 in spans)]
+    return [ins[lo:hi + 1] for lo, hi in inner]
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "foveated-360-video_amd", "lib", "libf360.so")
+    tmp, objs = code_objects(lib)
+    problems, seen = [], set()
+    try:
+        for obj in objs:
+            for name, ins in functions(obj).items():
+                texts = [t for _, t, _ in ins]
+                # the table writer proper: RGB0 / planar sources (1, 2, 3), LDS-staged stores (1);
+                # the byte-source fallback and the fused path's emit mode are built differently
+                if re.search(r"sat_write_kernelILi[123]ELi1EE", name):
+                    seen.add("writer")
+                    stores = [t for t in texts if t.startswith("global_store_dwordx4")]
+                    if any(" nt" not in t for t in stores):
+                        problems.append(f"{name}: a table store lost its nt bit")
+                    for lp in loops(ins):
+                        lt = [t for _, t, _ in lp]
+                        if any(t.startswith("global_store_dwordx") for t in lt) and \
+                                any(t.startswith("s_waitcnt vmcnt(0)") for t in lt):
+                            problems.append(f"{name}: s_waitcnt vmcnt(0) inside a storing loop "
+                                            f"({len(lt)} instructions)")
+                if re.search(r"sat_reduce_kernelILi[123]EE", name):
+                    seen.add("reducer")
+                    # the steady-state loop: a batch of >= 8 row loads, waits that count the
+                    # younger loads, no drain (the short loop that flushes a band's row sums
+                    # does drain, once per band)
+                    steady = [lt for lt in ([t for _, t, _ in lp] for lp in loops(ins))
+                              if sum(t.startswith("global_load_dword") for t in lt) >= 8 and
+                              any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in lt) and
+                              not any(t.startswith("s_waitcnt vmcnt(0)") for t in lt)]
+                    if not steady:
+                        problems.append(f"{name}: no row-batch loop with counted waits only")
+                if "sample_rect_stream_kernel" in name:
+                    seen.add("streamer")
+                    row_loops = [[t for _, t, _ in lp] for lp in loops(ins)
+                                 if any(t.startswith("global_load_lds_dwordx4") for _, t, _ in lp)]
+                    if not row_loops:
+                        problems.append(f"{name}: no loop with LDS-direct loads")
+                    for lt in row_loops:
+                        if any(t.startswith("s_waitcnt vmcnt(0)") for t in lt):
+                            problems.append(f"{name}: s_waitcnt vmcnt(0) inside the row loop")
+                        if not any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in lt):
+                            problems.append(f"{name}: the row loop has no counted vmcnt wait")
+                    if not any(t.startswith("global_store_short") and " nt" in t for t in texts):
+                        problems.append(f"{name}: pixel stores lost their nt bit")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for k in ("writer", "reducer", "streamer"):
+        if k not in seen:
+            problems.append(f"no {k} kernel found in {lib}")
+    if problems:
+        print("check_isa: FAILED\n  " + "\n  ".join(problems))
+        return 1
+    print(f"check_isa: ok ({len(objs)} gfx950 code objects; writer, reducer and streamer loops keep "
+          f"their counted waits, LDS-direct loads and nt stores)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Derives profiles/pmc_traffic.json from rocprofv3 PMC passes (scripts/pmc_s4.sh / prof.sh
+output directories) and stamps it with the hash of the kernel sources it was measured on:
+bench.py reports `roofline.traffic` only while that hash matches the tree it runs from.
+
+    python scripts/pmc_traffic.py <out.json> <pmc dir with FETCH_SIZE> <pmc dir with WRITE_SIZE> [yuv dirs...]
+    python scripts/pmc_traffic.py --hash          # the hash of the current csrc/
+"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_hash():
+    """sha256 over the HIP / C++ sources of the engine (file names and contents)."""
+    root = os.path.join(REPO, "foveated-360-video_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(root, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def means(path, counter):
+    acc = {}
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            acc.setdefault(name.split("<")[0], []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    if sys.argv[1:] == ["--hash"]:
+        print(csrc_hash())
+        return
+    out, fetch_dir, write_dir = sys.argv[1:4]
+    size = "7680x3840"
+    fetch, write = means(fetch_dir, "FETCH_SIZE"), means(write_dir, "WRITE_SIZE")
+    doc = {"_note": ("HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                     "(separate passes, KB units); FETCH_SIZE doubled for the kernels that read with "
+                     "wide coalesced 16-byte loads, as MI355X_MICROARCH.md prescribes for gfx950 "
+                     "(confirmed on the reducer: 57.7 MB reported for a 118 MB frame); WRITE_SIZE as "
+                     "is.  bench.py uses it only while csrc_sha equals the hash of its own csrc/."),
+           "csrc_sha": csrc_hash()}
+    for kernel, dbl in (("sat_write_kernel", 2), ("sat_reduce_kernel", 2), ("sat_carry_kernel", 2),
+                        ("sample_rect_stream_kernel", 2), ("sample_rect_walk_kernel", 1)):
+        if kernel in fetch and kernel in write:
+            doc[kernel] = {size: int(1024 * (dbl * fetch[kernel] + write[kernel]))}
+    if len(sys.argv) >= 6:
+        yf, yw = means(sys.argv[4], "FETCH_SIZE"), means(sys.argv[5], "WRITE_SIZE")
+        for kernel in ("sat_write_kernel", "sat_reduce_kernel"):
+            if kernel in yf and kernel in yw:
+                doc.setdefault(kernel, {})[size + ":yuv420p"] = int(1024 * (2 * yf[kernel] + yw[kernel]))
+    with open(out, "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps(doc))
+
+
+if __name__ == "__main__":
+    main()

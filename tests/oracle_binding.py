@@ -34,6 +34,9 @@ def lib() -> ctypes.CDLL:
         L.f360o_pipeline_encode_sample.restype = c_uint64
         L.f360o_pipeline_encode_sample.argtypes = [c_int, c_int, c_int, c_int, c_int, c_uint32,
                                                    POINTER(c_double)]
+        L.f360o_pipeline_compute.restype = c_uint64
+        L.f360o_pipeline_compute.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             POINTER(c_double)]
         L.f360o_lcg_fill.argtypes = [c_void_p, c_size_t, c_uint32]
         L.f360o_sat_encode.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int]
         L.f360o_satdec_grid.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
@@ -183,6 +186,16 @@ def pipeline_encode_sample(frames, src_w, src_h, out_w, out_h, seed0):
     sec = c_double(0.0)
     d = lib().f360o_pipeline_encode_sample(frames, src_w, src_h, out_w, out_h, seed0,
                                            ctypes.byref(sec))
+    return int(d), sec.value
+
+
+def pipeline_compute(frames, first_index, src_w, src_h, out_w, out_h):
+    """(digest, seconds) of the CPU hot path over frames synthesised beforehand
+    (frames: uint8 array [n, src_h, 4 * src_w]); the clock covers the compute only."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    sec = c_double(0.0)
+    d = lib().f360o_pipeline_compute(_ptr(frames), frames.shape[0], first_index, src_w, src_h,
+                                     out_w, out_h, ctypes.byref(sec))
     return int(d), sec.value
 
 

@@ -1,0 +1,66 @@
+"""CPU tier: bench.py's launch logic -- which frames each rank owns (weak default, BASELINE
+config 4's single batch of 64 sharded 8 per GPU), the command `--gpus N` starts by itself, and
+that the parent decides all of this without importing torch (it must not touch a GPU before it
+spawns the ranks).  Nothing here needs a device: `--dry-run` prints the plan and exits."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, "bench.py")
+
+
+def dry(*args, env=None):
+    out = subprocess.run([sys.executable, BENCH, "--dry-run", *args], capture_output=True, text=True,
+                         env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_single_gpu_plan_is_the_plain_command():
+    plan = dry()
+    assert plan["gpus"] == 1 and plan["scaling"] == "weak"
+    assert plan["ranks"] == [{"rank": 0, "frames": [0, 64]}]
+    assert plan["launch"][1:] == [BENCH]          # no launcher around N = 1
+
+
+def test_global_batch_64_over_8_gpus_is_8_frames_each():
+    plan = dry("--gpus", "8", "--global-batch", "64", "--steps", "5", "--warmup", "2")
+    assert plan["scaling"] == "strong" and plan["frames_total"] == 64
+    assert [r["frames"] for r in plan["ranks"]] == [[8 * k, 8 * k + 8] for k in range(8)]
+    cmd = plan["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    # the ranks get the user's arguments unchanged (and not --dry-run)
+    tail = cmd[cmd.index(BENCH) + 1:]
+    assert tail == ["--gpus", "8", "--global-batch", "64", "--steps", "5", "--warmup", "2"]
+
+
+def test_weak_default_gives_every_rank_its_own_batch():
+    plan = dry("--gpus", "4", "--batch", "16")
+    assert plan["scaling"] == "weak" and plan["frames_total"] == 64
+    assert [r["frames"] for r in plan["ranks"]] == [[0, 16], [16, 32], [32, 48], [48, 64]]
+    # uneven single batch: blocks differ by at most one frame and cover it exactly once
+    plan = dry("--gpus", "3", "--global-batch", "64")
+    sizes = [b - a for a, b in (r["frames"] for r in plan["ranks"])]
+    assert sorted(sizes) == [21, 21, 22] and plan["ranks"][0]["frames"][0] == 0
+    assert plan["ranks"][-1]["frames"][1] == 64
+
+
+def test_rank_count_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True,
+                         env=env, timeout=120)
+    assert out.returncode == 2 and "must agree" in out.stderr
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--global-batch", "4"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "without a frame" in out.stderr
+
+
+def test_parent_plans_without_importing_torch():
+    code = ("import runpy, sys; sys.argv = ['bench.py', '--gpus', '2', '--dry-run']; "
+            "runpy.run_path(%r, run_name='__main__'); "
+            "assert 'torch' not in sys.modules, 'the launching parent imported torch'" % BENCH)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr

@@ -64,3 +64,15 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(root, fn), errors="ignore").read()
                 assert "oracle_binding" not in text and "f360o_" not in text, fn
                 assert "f360_oracle" not in text, fn
+
+
+def test_inner_loops_keep_their_memory_pipeline_tricks():
+    """scripts/check_isa.py on the built library: the writer / reducer / sampler loops still wait
+    with counted vmcnt, store non-temporally and load LDS-directly (a toolchain bump that undid
+    this would pass every parity test and cost 20-40 %)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "scripts", "check_isa.py")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -713,6 +713,40 @@ def test_one_context_per_thread(f360, oracle):
     assert not errors, errors
 
 
+def test_two_contexts_on_two_devices_from_one_thread(f360, oracle):
+    """Every C-ABI entry binds its context's device (and puts the caller's back): one thread
+    interleaves encode and sample on contexts of two GPUs.  Needs two devices; the round-end
+    8-GPU node has them, the single-GPU build box skips."""
+    if f360.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    w, h = 640, 320
+    rw, rh = reduced(w), reduced(h)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    ctxs = [f360.Context(0), f360.Context(1)]
+    encs = [f360.SATEncoder(c) for c in ctxs]
+    decs = [f360.SATDecoder(c) for c in ctxs]
+    frames = [oracle.lcg_frame(w, h, 900 + k) for k in range(2)]
+    srcs = [c.upload(f) for c, f in zip(ctxs, frames)]
+    sats = [c.malloc(w * h * 12) for c in ctxs]
+    reds = [c.malloc(rh * 4 * rw) for c in ctxs]
+    for r in reds:
+        r.fill(0xA5)
+    for k in (0, 1, 0, 1):   # interleaved, no synchronisation in between
+        encs[k].EncodeFrameGPU(sats[k].ptr, srcs[k].ptr, w, h, 4 * w)
+    for k in (1, 0):
+        decs[k].SampleFrameRectGPU(reds[k].ptr, rw, rh, 4 * rw, sats[k].ptr, (w, h), 0.3 + 0.4 * k, 0.6)
+    for k in range(2):
+        want_sat = oracle.sat_encode(frames[k], w, h, 4 * w)
+        want = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, 4 * rw, want_sat, w, h, grid, 0.3 + 0.4 * k, 0.6)
+        assert np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want_sat), k
+        assert np.array_equal(reds[k].copy_to_host(np.uint8, (rh, 4 * rw)), want), k
+    for d in decs:
+        d.close()
+    for c in ctxs:
+        c.close()
+
+
 def test_encode_sample_inside_a_hip_graph(f360, oracle):
     """The launch functions allocate nothing once prepared, so the path can be captured into a
     hipGraph (here through torch's CUDAGraph on the stream the context borrows) and replayed."""
