@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <iostream>
 
+#include "cpu_twins.h"
 #include "opencl_manager.h"
 
 #ifndef ROUND_UP_TO
@@ -147,5 +148,53 @@ class ImageSampler {
     if (ret != F360_OK)
       std::cerr << "[ImageSampler::ExpandSampledFrame] kernel launch failed:" << ret << " "
                 << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
+ public:
+  // ---- host twins (f360/cpu_twins.h), templated on the frame / codec-context types
+  // src/image_sampler.cc:302-356 ("Untested" there): point sample of a uint32 buffer with
+  // four elements per pixel
+  template <class Frame, class CodecContext>
+  void SampleFrameRectCPU(Frame *target_frame, uint32_t *buffer, CodecContext *codec_ctx,
+                          float center_x, float center_y) {
+    f360cpu::sample_rect_point(target_frame->data[0], target_frame->width, target_frame->height,
+                               target_frame->linesize[0], buffer, codec_ctx->width,
+                               codec_ctx->height, center_x, center_y);
+  }
+  // src/image_sampler.cc:358-419
+  template <class Frame>
+  void ExpandSampledFrameRectCPU(Frame *target_frame, Frame *source_frame, float center_x,
+                                 float center_y) {
+    f360cpu::expand_rect(target_frame->data[0], target_frame->width, target_frame->height,
+                         target_frame->linesize[0], source_frame->data[0], source_frame->width,
+                         source_frame->height, source_frame->linesize[0], center_x, center_y);
+  }
+  // src/image_sampler.cc:421-575
+  template <class Frame>
+  void InterpolateFrameRectCPU(Frame *target_frame, Frame *source_frame, float center_x,
+                               float center_y) {
+    f360cpu::interpolate_rect(target_frame->data[0], target_frame->width, target_frame->height,
+                              target_frame->linesize[0], source_frame->data[0],
+                              source_frame->width, source_frame->height,
+                              source_frame->linesize[0], center_x, center_y);
+  }
+  // src/image_sampler.cc:623-666
+  template <class Frame>
+  void ExpandSampledFrameLogPolarCPU(Frame *target_frame, Frame *source_frame, float center_x,
+                                     float center_y) {
+    f360cpu::expand_logpolar(target_frame->data[0], target_frame->width, target_frame->height,
+                             target_frame->linesize[0], source_frame->data[0],
+                             source_frame->width, source_frame->height,
+                             source_frame->linesize[0], center_x, center_y);
+  }
+  // src/image_sampler.cc:668-778
+  template <class Frame>
+  void InterpolateFrameLogPolarCPU(Frame *target_frame, Frame *source_frame, float center_x,
+                                   float center_y) {
+    f360cpu::interpolate_logpolar(target_frame->data[0], target_frame->width,
+                                  target_frame->height, target_frame->linesize[0],
+                                  source_frame->data[0], source_frame->width,
+                                  source_frame->height, source_frame->linesize[0], center_x,
+                                  center_y);
   }
 };

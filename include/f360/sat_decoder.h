@@ -2,16 +2,19 @@
 // (device methods).  The AVCodecContext* parameter of SampleFrameRectGPU is a
 // template: the reference reads only ->width / ->height (src/sat_decoder.cc
 // :328-329), so a real AVCodecContext or any struct with those fields works.
-// Not provided: the CPU twins (oracle/ holds the CPU restatement, as test
-// infrastructure) and the experimental SVD pair CreateReducedSAT /
-// SampleFrameFromReducedSAT and SampleFrameRectGPU360 (no caller in the
-// reference; SURVEY.md 2.1 #2f, 2.2).
+// The CPU twins DecodeFrameCPU / ExpandSampledFrameRectCPU / InterpolateFrameRectCPU
+// are the host implementations of f360/cpu_twins.h.  Not provided: SampleFrameRectCPU
+// (src/sat_decoder.cc:400-532 reads its 3-element table with a 4-element row
+// stride -- wrong rows, out of bounds below 3/4 of the height: SURVEY.md 8a-10) and
+// the experimental SVD pair CreateReducedSAT / SampleFrameFromReducedSAT and
+// SampleFrameRectGPU360 (no caller in the reference; SURVEY.md 2.1 #2f, 2.2).
 #pragma once
 
 #include <cstdint>
 #include <cstdlib>
 #include <iostream>
 
+#include "cpu_twins.h"
 #include "opencl_manager.h"
 
 class SATDecoder {
@@ -156,5 +159,32 @@ class SATDecoder {
                 << ret << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
       exit(EXIT_FAILURE);  // :924
     }
+  }
+
+  // ---- host twins (f360/cpu_twins.h), templated on the frame / codec-context types: anything
+  // with ->width, ->height, ->data[0], ->linesize[0] (an AVFrame, an AVCodecContext)
+  // src/sat_decoder.cc:212-299 (prints the size like the reference does)
+  template <class Frame, class CodecContext>
+  void DecodeFrameCPU(Frame *target_frame, uint32_t *buffer, CodecContext *codec_ctx) {
+    std::cout << "width: " << codec_ctx->width << ", height: " << codec_ctx->height << std::endl;
+    f360cpu::decode_frame(target_frame->data[0], target_frame->linesize[0], buffer,
+                          codec_ctx->width, codec_ctx->height);
+  }
+  // src/sat_decoder.cc:555-616
+  template <class Frame>
+  void ExpandSampledFrameRectCPU(Frame *target_frame, Frame *source_frame, float center_x,
+                                 float center_y) {
+    f360cpu::expand_rect(target_frame->data[0], target_frame->width, target_frame->height,
+                         target_frame->linesize[0], source_frame->data[0], source_frame->width,
+                         source_frame->height, source_frame->linesize[0], center_x, center_y);
+  }
+  // src/sat_decoder.cc:618-772
+  template <class Frame>
+  void InterpolateFrameRectCPU(Frame *target_frame, Frame *source_frame, float center_x,
+                               float center_y) {
+    f360cpu::interpolate_rect(target_frame->data[0], target_frame->width, target_frame->height,
+                              target_frame->linesize[0], source_frame->data[0],
+                              source_frame->width, source_frame->height,
+                              source_frame->linesize[0], center_x, center_y);
   }
 };

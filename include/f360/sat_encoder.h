@@ -1,13 +1,14 @@
 // f360/sat_encoder.h -- drop-in for the reference's src/sat_encoder.h:22-43.
 // Same class name, constructors and GPU method signature; the body calls the
-// HIP engine through the C ABI.  EncodeFrameCPU is not provided: the product
-// path has no CPU implementation (the CPU restatement lives under oracle/ and
-// is test infrastructure).
+// HIP engine through the C ABI.  EncodeFrameCPU (src/sat_encoder.cc:137-185) is
+// the host implementation of f360/cpu_twins.h, templated on the codec-context /
+// frame types (anything with ->width, ->height / ->data[0], ->linesize[0]).
 #pragma once
 
 #include <cstdint>
 #include <iostream>
 
+#include "cpu_twins.h"
 #include "opencl_manager.h"
 
 class SATEncoder {
@@ -34,6 +35,13 @@ class SATEncoder {
     if (ret != F360_OK)
       std::cerr << "[SATEncoder::EncodeFrameGPU] kernel launch failed:" << ret << " "
                 << f360_last_error_string() << std::endl;
+  }
+
+  // src/sat_encoder.cc:137-185: the same table on the host (uint32 [height][width][3]).
+  template <class CodecContext, class Frame>
+  void EncodeFrameCPU(uint32_t *target_frame, CodecContext *codec_ctx, Frame *frame) {
+    f360cpu::encode_frame(target_frame, codec_ctx->width, codec_ctx->height, frame->data[0],
+                          frame->linesize[0]);
   }
 
   // Not in the reference: the table of the RGB0 frame sws_scale would make of a decoder's
