@@ -12,7 +12,11 @@
 // the sleep) and aggregate input Mpixels/s: BASELINE.json config 5.
 //
 //   ./send_frame_loop_synth <clients> <fps> <frames> <width> <height> [trace.txt] [gpus]
-// client c runs on GPU c % gpus.  Prints one JSON line.
+//                           [rgb0|yuv420p (source layout)] [rgb0|yuv420p (delivered layout)]
+// client c runs on GPU c % gpus.  Prints one JSON line.  With "yuv420p" as the delivered layout
+// the reduced frame is converted on the device (f360_rgb0_to_yuv420p, the sws_scale of
+// VideoEncoder::EncodeFrame, src/video_encoder.cc:380-395) and 1.5 instead of 4 bytes per pixel
+// come back over PCIe; the digest then covers the three planes.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -54,7 +58,8 @@ static uint64_t fnv1a64(const void *p, size_t n) {
 }
 
 static void client_loop(int client, int device, double fps, int frames, int width, int height,
-                        const GazeViewPoints *trace, bool planar, ClientResult *out) {
+                        const GazeViewPoints *trace, bool planar, bool planar_out,
+                        ClientResult *out) {
   using clock = std::chrono::high_resolution_clock;
   // ---- InitializeConnectionData (video_server.cc:62-66) --------------------------------
   OpenCLManager cl_manager;
@@ -77,6 +82,10 @@ static void client_loop(int client, int device, double fps, int frames, int widt
                            (size_t)3 * width * height * sizeof(uint32_t));
   const size_t cl_output_buffer_size = (size_t)out_linesize * out_h;
   cl::Buffer cl_output_buffer(cl_manager.context, CL_MEM_READ_WRITE, cl_output_buffer_size);
+  // delivered as planes: Y, U, V back to back, tight rows
+  const size_t oy_bytes = (size_t)out_w * out_h, oc_bytes = oy_bytes / 4;
+  const size_t delivered_size = planar_out ? oy_bytes + 2 * oc_bytes : cl_output_buffer_size;
+  cl::Buffer cl_yuv_buffer(cl_manager.context, CL_MEM_READ_WRITE, planar_out ? delivered_size : 16);
 
   // synthetic decoder: a few pre-staged pinned frames, cycled
   const int pool = 3;
@@ -94,6 +103,7 @@ static void client_loop(int client, int device, double fps, int frames, int widt
   std::memset(output_frame, 0, cl_output_buffer_size);
   cl::copy(cl_manager.command_queue, output_frame, output_frame + cl_output_buffer_size,
            cl_output_buffer);
+  std::memset(output_frame, 0, delivered_size);
 
   auto checkpoint_time = clock::now();
   const auto loop_start = checkpoint_time;
@@ -131,8 +141,21 @@ static void client_loop(int client, int device, double fps, int frames, int widt
     const auto t2 = clock::now();
     sat_decoder.SampleFrameRectGPU(cl_output_buffer(), out_w, out_h, out_linesize, cl_sat_buffer(),
                                    &codec, center_x, center_y);
-    ret |= cl::copy(cl_manager.command_queue, cl_output_buffer, output_frame,
-                    output_frame + cl_output_buffer_size);
+    if (planar_out) {
+      uint8_t *yb = static_cast<uint8_t *>(cl_yuv_buffer());
+      if (f360_rgb0_to_yuv420p(cl_manager.command_queue.ctx(), yb, yb + oy_bytes,
+                               yb + oy_bytes + oc_bytes, out_w, out_w / 2, out_w / 2,
+                               static_cast<const uint8_t *>(cl_output_buffer()), out_linesize,
+                               out_w, out_h) != F360_OK) {
+        std::cerr << "f360_rgb0_to_yuv420p: " << f360_last_error_string() << std::endl;
+        exit(EXIT_FAILURE);
+      }
+      ret |= cl::copy(cl_manager.command_queue, cl_yuv_buffer, output_frame,
+                      output_frame + delivered_size);
+    } else {
+      ret |= cl::copy(cl_manager.command_queue, cl_output_buffer, output_frame,
+                      output_frame + cl_output_buffer_size);
+    }
     const auto t3 = clock::now();
     if (ret != CL_SUCCESS) {
       std::cerr << "Failed to copy output frame out. " << ret << std::endl;
@@ -145,7 +168,7 @@ static void client_loop(int client, int device, double fps, int frames, int widt
     ++out->frames;
   }
   out->loop_s = std::chrono::duration<double>(clock::now() - loop_start).count();
-  out->last_digest = fnv1a64(output_frame, cl_output_buffer_size);
+  out->last_digest = fnv1a64(output_frame, delivered_size);
   for (int k = 0; k < pool; ++k) f360_host_free_pinned(staged[k]);
   f360_host_free_pinned(output_frame);
 }
@@ -159,6 +182,7 @@ int main(int argc, char **argv) {
   const std::string trace_path = argc > 6 ? argv[6] : "";
   int gpus = argc > 7 ? atoi(argv[7]) : 0;
   const bool planar = argc > 8 && std::string(argv[8]) == "yuv420p";
+  const bool planar_out = argc > 9 && std::string(argv[9]) == "yuv420p";
   if (gpus <= 0 && f360_device_count(&gpus) != F360_OK) {
     std::cerr << f360_last_error_string() << std::endl;
     return EXIT_FAILURE;
@@ -171,7 +195,8 @@ int main(int argc, char **argv) {
   const auto t0 = std::chrono::high_resolution_clock::now();
   for (int c = 0; c < clients; ++c)
     threads.emplace_back(client_loop, c, c % gpus, fps, frames, width, height,
-                         trace.points.empty() ? nullptr : &trace, planar, &results[(size_t)c]);
+                         trace.points.empty() ? nullptr : &trace, planar, planar_out,
+                         &results[(size_t)c]);
   for (auto &t : threads) t.join();
   const double wall_s =
       std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -188,11 +213,12 @@ int main(int argc, char **argv) {
   }
   std::sort(all.begin(), all.end());
   auto pct = [&](double q) { return all.empty() ? 0.0 : all[(size_t)std::min<double>(all.size() - 1, q * all.size())]; };
-  printf("{\"source\": \"%s\", \"clients\": %d, \"gpus\": %d, \"fps_target\": %.1f, \"frames_per_client\": %d, \"width\": %d, "
+  printf("{\"source\": \"%s\", \"delivered\": \"%s\", \"clients\": %d, \"gpus\": %d, \"fps_target\": %.1f, \"frames_per_client\": %d, \"width\": %d, "
          "\"height\": %d, \"wall_s_with_setup\": %.3f, \"fps_achieved_per_client\": %.2f, \"mpix_per_s\": %.1f, "
          "\"latency_ms_p50\": %.3f, \"latency_ms_p99\": %.3f, \"latency_ms_max\": %.3f, "
          "\"client0_last_gaze\": [%.9g, %.9g], \"client0_last_digest\": \"%016llx\", \"last_digests\": [",
-         planar ? "yuv420p" : "rgb0", clients, gpus, fps, frames, width, height, wall_s,
+         planar ? "yuv420p" : "rgb0", planar_out ? "yuv420p" : "rgb0", clients, gpus, fps, frames, width,
+         height, wall_s,
          fps_sum / clients,
          loop_max > 0 ? (double)total_frames * width * height / 1e6 / loop_max : 0.0, pct(0.50), pct(0.99),
          all.empty() ? 0.0 : all.back(), results[0].last_gaze[0], results[0].last_gaze[1],

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "f360_sat_encode_prepare": (c_int, [c_void_p, c_int, c_int]),
     "f360_yuv420p_to_rgb0": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int]),
+    "f360_rgb0_to_yuv420p": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_void_p, c_int, c_int, c_int]),
     "f360_sat_encode_yuv420p": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int]),
     "f360_satdec_create": (c_int, [c_void_p, POINTER(c_void_p)]),
@@ -215,6 +217,12 @@ class Context:
         """The sws_scale of VideoDecoder::GetFrame (video_decoder.cc:222-224) on the device."""
         _check(lib().f360_yuv420p_to_rgb0(self._h, _p(dst), dst_linesize, _p(y), _p(u), _p(v),
                                           y_linesize, u_linesize, v_linesize, width, height))
+
+    def rgb0_to_yuv420p(self, y, u, v, y_linesize: int, u_linesize: int, v_linesize: int, src,
+                        src_linesize: int, width: int, height: int) -> None:
+        """The sws_scale of VideoEncoder::EncodeFrame (video_encoder.cc:380-395) on the device."""
+        _check(lib().f360_rgb0_to_yuv420p(self._h, _p(y), _p(u), _p(v), y_linesize, u_linesize,
+                                          v_linesize, _p(src), src_linesize, width, height))
 
     def expand_rect(self, dst, dst_w, dst_h, dst_linesize, src, src_w, src_h, src_linesize,
                     center_x, center_y) -> None:

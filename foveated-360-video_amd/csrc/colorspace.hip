@@ -1,4 +1,5 @@
-// colorspace.hip -- planar YUV 4:2:0 -> RGB0 on the device.
+// colorspace.hip -- planar YUV 4:2:0 <-> RGB0 on the device, the colour-space steps either side
+// of the hot path (the second half of this file is the output side, RGB0 -> yuv420p).
 //
 // Replaces the CPU sws_scale call in front of the hot path: VideoDecoder::GetFrame converts every
 // decoded frame with sws_getContext(w, h, yuv420p, w, h, AV_PIX_FMT_RGB0, SWS_BILINEAR) +
@@ -118,6 +119,211 @@ extern "C" int f360_yuv420p_to_rgb0(f360_ctx *ctx, uint8_t *dst_dev, int dst_lin
       hipLaunchKernelGGL(yuv420p_to_rgb0_px_kernel<0>, grid, dim3(256), 0, ctx->stream, dst_dev,
                          dst_linesize, p, width, height, k);
   }
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+
+// ================================================================================================
+// RGB0 -> planar YUV 4:2:0: the sws_scale of VideoEncoder::EncodeFrame in front of NVENC
+// (src/video_encoder.cc:380-395: sws_getContext(w, h, RGB0, w, h, AV_PIX_FMT_YUV420P,
+// SWS_BILINEAR) + sws_scale on the CPU).  On the device the reduced frame can leave as 1.5
+// instead of 4 bytes per pixel.
+//
+// FFmpeg 4.2 has no special converter for this pair: the generic scaler runs (paths relative to
+// include/FFmpeg42/libswscale/).  What it computes, for even sizes:
+//   Y14 = (RY R + GY G + BY B + (32 << 14) + (1 << 8)) >> 9      input.c:252-275 (rgb32ToY_c; the
+//         x86 asm ff_rgbaToY_sse2 has the same rounding constant, x86/input.asm)
+//   U14 = (RU sR + GU sG + BU sB + (256 << 15) + (1 << 9)) >> 10  over the PAIR of pixels
+//         (sums sR = R0 + R1 ...), V14 likewise                   input.c:304-346 (rgb32ToUV_half_c)
+//   one-tap horizontal filter 1 << 14, shifted by 13: x15 = min(2 x14, 32767)   swscale.c:95-121
+//   Y  = clip8((Y15 + 64) >> 7)                                   output.c:395-403
+//   chroma rows are halved by the bilinear 2:1 filter initFilter produces (utils.c:331-726):
+//   taps 512, 1536, 1536, 512 on source rows 2c - 1 .. 2c + 2, folded at the borders into
+//   2048, 1536, 512 (first row) and 512, 1536, 2048 (last row);
+//   C builds:   U = clip8(((64 << 12) + sum_j U15_j f_j) >> 19)    output.c:380-393
+//   x86 builds: U = clip8((5 + sum_j ((U15_j f_j) >> 16)) >> 3) -- pmulhw truncates every tap,
+//               5 = (64 + ((4 - 1) << 3)) >> 4 (x86/swscale.c:209-248) -- for every chroma row
+//               but the last, which the C function computes (swscale.c:497-504).
+// "yuv.model" selects the build reproduced, as on the input side.  The coefficients are the
+// ITU-R 601 limited-range set of utils.c:811-821.
+namespace {
+
+struct Rgb2YuvConsts {
+  int ry, gy, by, ru, gu, bu, rv, gv, bv;
+};
+
+__host__ __device__ inline Rgb2YuvConsts rgb2yuv_consts() {
+  Rgb2YuvConsts k;
+  k.ry = (int)(0.299 * 219 / 255 * (1 << 15) + 0.5);
+  k.gy = (int)(0.587 * 219 / 255 * (1 << 15) + 0.5);
+  k.by = (int)(0.114 * 219 / 255 * (1 << 15) + 0.5);
+  k.ru = -(int)(0.169 * 224 / 255 * (1 << 15) + 0.5);
+  k.gu = -(int)(0.331 * 224 / 255 * (1 << 15) + 0.5);
+  k.bu = (int)(0.500 * 224 / 255 * (1 << 15) + 0.5);
+  k.rv = (int)(0.500 * 224 / 255 * (1 << 15) + 0.5);
+  k.gv = -(int)(0.419 * 224 / 255 * (1 << 15) + 0.5);
+  k.bv = -(int)(0.081 * 224 / 255 * (1 << 15) + 0.5);
+  return k;
+}
+
+__device__ __forceinline__ int luma15(const Rgb2YuvConsts &k, uint32_t px) {
+  const int r = px & 0xff, g = (px >> 8) & 0xff, b = (px >> 16) & 0xff;
+  const int y14 = (k.ry * r + k.gy * g + k.by * b + (32 << 14) + (1 << 8)) >> 9;
+  return min(2 * y14, 32767);
+}
+// chroma of a pixel pair, 15 bits: .x = U, .y = V
+__device__ __forceinline__ int2 chroma15(const Rgb2YuvConsts &k, uint32_t p0, uint32_t p1) {
+  const int r = (int)(p0 & 0xff) + (int)(p1 & 0xff);
+  const int g = (int)((p0 >> 8) & 0xff) + (int)((p1 >> 8) & 0xff);
+  const int b = (int)((p0 >> 16) & 0xff) + (int)((p1 >> 16) & 0xff);
+  const int u14 = (k.ru * r + k.gu * g + k.bu * b + (256 << 15) + (1 << 9)) >> 10;
+  const int v14 = (k.rv * r + k.gv * g + k.bv * b + (256 << 15) + (1 << 9)) >> 10;
+  return make_int2(min(2 * u14, 32767), min(2 * v14, 32767));
+}
+__device__ __forceinline__ uint32_t clip8(int v) { return (uint32_t)min(max(v, 0), 255); }
+
+// A thread owns PAIRS chroma samples of one chroma row: 2 * PAIRS pixels of the four source
+// rows its vertical filter needs, the luma of the two rows it is centred on.  PAIRS = 4: 32-byte
+// row pieces, 8-byte luma stores, 4-byte chroma stores; PAIRS = 1: any even width / alignment.
+template <int MODEL, int PAIRS>
+__global__ __launch_bounds__(256) void rgb0_to_yuv420p_kernel(
+    uint8_t *__restrict__ y_dst, uint8_t *__restrict__ u_dst, uint8_t *__restrict__ v_dst,
+    int y_linesize, int u_linesize, int v_linesize, const uint8_t *__restrict__ src,
+    int src_linesize, int width, int height, const Rgb2YuvConsts k) {
+  const int c0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * PAIRS;  // first chroma column
+  const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);             // chroma row
+  const int cw = width >> 1, ch = height >> 1;
+  if (c0 >= cw || cy >= ch) return;
+  // taps and source rows: interior 512 1536 1536 512 on rows 2cy-1 .. 2cy+2; the first row
+  // folds the tap above the frame into its neighbour, the last row the tap below
+  int rows[4], taps[4];
+  if (cy == 0) {
+    rows[0] = 0; rows[1] = 1; rows[2] = 2; rows[3] = 2;
+    taps[0] = 2048; taps[1] = 1536; taps[2] = 512; taps[3] = 0;
+  } else if (cy == ch - 1) {
+    rows[0] = height - 3; rows[1] = height - 3; rows[2] = height - 2; rows[3] = height - 1;
+    taps[0] = 0; taps[1] = 512; taps[2] = 1536; taps[3] = 2048;
+  } else {
+    for (int j = 0; j < 4; ++j) {
+      rows[j] = 2 * cy - 1 + j;
+      taps[j] = j == 0 || j == 3 ? 512 : 1536;
+    }
+  }
+  // x86 builds: every chroma row but the last through the truncating 16-bit multiply
+  const bool mmx = MODEL == 1 && cy < ch - 1;
+  int acc_u[PAIRS], acc_v[PAIRS];
+#pragma unroll
+  for (int q = 0; q < PAIRS; ++q) acc_u[q] = acc_v[q] = mmx ? 5 : (64 << 12);
+  uint32_t ylo0[(PAIRS + 1) / 2], ylo1[(PAIRS + 1) / 2];  // luma bytes of rows 2cy, 2cy+1
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint8_t *row = src + (size_t)rows[j] * src_linesize + (size_t)c0 * 8;
+    uint32_t px[2 * PAIRS];
+    if (PAIRS == 4) {
+      typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
+      const u32x4_r a = *reinterpret_cast<const u32x4_r *>(row);
+      const u32x4_r b = *reinterpret_cast<const u32x4_r *>(row + 16);
+      px[0] = a[0]; px[1] = a[1]; px[2] = a[2]; px[3] = a[3];
+      px[4] = b[0]; px[5] = b[1]; px[6] = b[2]; px[7] = b[3];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2 * PAIRS; ++q)
+        px[q] = (uint32_t)row[4 * q] | ((uint32_t)row[4 * q + 1] << 8) | ((uint32_t)row[4 * q + 2] << 16);
+    }
+#pragma unroll
+    for (int q = 0; q < PAIRS; ++q) {
+      const int2 c = chroma15(k, px[2 * q], px[2 * q + 1]);
+      if (mmx) {
+        acc_u[q] = (int)(int16_t)(acc_u[q] + ((c.x * taps[j]) >> 16));
+        acc_v[q] = (int)(int16_t)(acc_v[q] + ((c.y * taps[j]) >> 16));
+      } else {
+        acc_u[q] += c.x * taps[j];
+        acc_v[q] += c.y * taps[j];
+      }
+    }
+    // the luma rows: source rows 2cy and 2cy+1 are taps 1 and 2 of an interior chroma row, taps
+    // 0 and 1 of the first, 2 and 3 of the last
+    const int lr = rows[j] - 2 * cy;
+    if (lr == 0 || lr == 1) {
+      uint32_t w[(PAIRS + 1) / 2];
+#pragma unroll
+      for (int q = 0; q < 2 * PAIRS; ++q) {
+        const uint32_t yv = clip8((luma15(k, px[q]) + 64) >> 7);
+        if ((q & 3) == 0) w[q >> 2] = yv;
+        else w[q >> 2] |= yv << (8 * (q & 3));
+      }
+#pragma unroll
+      for (int q = 0; q < (PAIRS + 1) / 2; ++q) {
+        if (lr == 0) ylo0[q] = w[q];
+        else ylo1[q] = w[q];
+      }
+    }
+  }
+  uint32_t ub = 0, vb = 0;
+#pragma unroll
+  for (int q = 0; q < PAIRS; ++q) {
+    ub |= clip8(mmx ? acc_u[q] >> 3 : acc_u[q] >> 19) << (8 * q);
+    vb |= clip8(mmx ? acc_v[q] >> 3 : acc_v[q] >> 19) << (8 * q);
+  }
+  uint8_t *yo0 = y_dst + (size_t)(2 * cy) * y_linesize + (size_t)c0 * 2;
+  uint8_t *yo1 = yo0 + y_linesize;
+  uint8_t *uo = u_dst + (size_t)cy * u_linesize + c0, *vo = v_dst + (size_t)cy * v_linesize + c0;
+  if (PAIRS == 4) {
+    *reinterpret_cast<uint2 *>(yo0) = make_uint2(ylo0[0], ylo0[PAIRS == 4 ? 1 : 0]);
+    *reinterpret_cast<uint2 *>(yo1) = make_uint2(ylo1[0], ylo1[PAIRS == 4 ? 1 : 0]);
+    *reinterpret_cast<uint32_t *>(uo) = ub;
+    *reinterpret_cast<uint32_t *>(vo) = vb;
+  } else {
+    yo0[0] = (uint8_t)ylo0[0];
+    yo0[1] = (uint8_t)(ylo0[0] >> 8);
+    yo1[0] = (uint8_t)ylo1[0];
+    yo1[1] = (uint8_t)(ylo1[0] >> 8);
+    uo[0] = (uint8_t)ub;
+    vo[0] = (uint8_t)vb;
+  }
+}
+
+}  // namespace
+
+extern "C" int f360_rgb0_to_yuv420p(f360_ctx *ctx, uint8_t *y_dev, uint8_t *u_dev, uint8_t *v_dev,
+                                    int y_linesize, int u_linesize, int v_linesize,
+                                    const uint8_t *src_dev, int src_linesize, int width,
+                                    int height) {
+  F360_REQUIRE(ctx, "f360_rgb0_to_yuv420p: null context");
+  F360_REQUIRE(y_dev && u_dev && v_dev && src_dev, "f360_rgb0_to_yuv420p: null buffer");
+  // odd sizes change libswscale's chroma geometry (ceil'ed plane sizes, a non-integer vertical
+  // step); below 8 rows initFilter shortens the vertical filter: neither is provided
+  F360_REQUIRE(width >= 2 && height >= 8 && width % 2 == 0 && height % 2 == 0,
+               "f360_rgb0_to_yuv420p: bad size %dx%d (even width, even height >= 8)", width,
+               height);
+  F360_REQUIRE(src_linesize >= 4 * width && y_linesize >= width && u_linesize >= width / 2 &&
+                   v_linesize >= width / 2,
+               "f360_rgb0_to_yuv420p: linesize too small");
+  F360_BIND_DEVICE(ctx);
+  const Rgb2YuvConsts k = rgb2yuv_consts();
+  const bool vec = width % 8 == 0 && src_linesize % 16 == 0 && y_linesize % 8 == 0 &&
+                   u_linesize % 4 == 0 && v_linesize % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(src_dev) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(y_dev) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(u_dev) & 3) == 0 &&
+                   (reinterpret_cast<uintptr_t>(v_dev) & 3) == 0;
+  const bool prof = f360::take_profile_slot(ctx);
+  f360::KernelSpan span(ctx, f360::kRgbToYuv, prof);
+  const bool x86 = ctx->opt_yuv_model == 1;
+  const int cw = width / 2, ch = height / 2;
+#define F360_R2Y(M, P)                                                                          \
+  hipLaunchKernelGGL((rgb0_to_yuv420p_kernel<M, P>), dim3(((cw + P - 1) / P + 63) / 64, (ch + 3) / 4), \
+                     dim3(256), 0, ctx->stream, y_dev, u_dev, v_dev, y_linesize, u_linesize,    \
+                     v_linesize, src_dev, src_linesize, width, height, k)
+  if (vec) {
+    if (x86) F360_R2Y(1, 4);
+    else F360_R2Y(0, 4);
+  } else {
+    if (x86) F360_R2Y(1, 1);
+    else F360_R2Y(0, 1);
+  }
+#undef F360_R2Y
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

@@ -106,6 +106,7 @@ enum KernelId {
   kFovMaps,
   kFovSample,
   kYuvToRgb,
+  kRgbToYuv,
   kExpand,
   kKernelCount
 };

@@ -314,7 +314,7 @@ static const char *const kKernelNames[f360::kKernelCount] = {
     "is_sample_rect_kernel",    "is_sample_logpolar_kernel",
     "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel",
     "foveate_maps_kernel",      "sample_compact_kernel",  "yuv420p_to_rgb0_kernel",
-    "expand_kernel"};
+    "rgb0_to_yuv420p_kernel",   "expand_kernel"};
 
 int f360_kernel_count(void) { return f360::kKernelCount; }
 

@@ -118,6 +118,18 @@ int f360_yuv420p_to_rgb0(f360_ctx *ctx, uint8_t *dst_dev, int dst_linesize,
                          const uint8_t *y_dev, const uint8_t *u_dev, const uint8_t *v_dev,
                          int y_linesize, int u_linesize, int v_linesize, int width,
                          int height);
+/* The colour-space step BEHIND the path: replaces the CPU sws_scale of VideoEncoder::EncodeFrame
+ * in front of NVENC (src/video_encoder.cc:380-395: sws_getContext(w, h, RGB0, w, h,
+ * AV_PIX_FMT_YUV420P, SWS_BILINEAR) + sws_scale): RGB0 -> planar 8-bit YUV 4:2:0, ITU-R 601
+ * limited range.  FFmpeg 4.2 runs its generic scaler for this pair (rgb32ToY_c /
+ * rgb32ToUV_half_c input conversion, include/FFmpeg42/libswscale/input.c:252-346; one-tap
+ * horizontal filters; chroma rows halved by the 4-tap bilinear filter of utils.c:331-726);
+ * "yuv.model" 1 (default) reproduces x86 builds, whose vertical chroma scaler truncates every
+ * tap's product (x86/swscale.c:201-275), 0 the C functions (output.c:380-403).  Even width,
+ * even height >= 8.  The fourth byte of the source pixels is ignored. */
+int f360_rgb0_to_yuv420p(f360_ctx *ctx, uint8_t *y_dev, uint8_t *u_dev, uint8_t *v_dev,
+                         int y_linesize, int u_linesize, int v_linesize,
+                         const uint8_t *src_dev, int src_linesize, int width, int height);
 /* f360_yuv420p_to_rgb0 + f360_sat_encode in one pass: the table of the RGB0 frame the call
  * above would write, computed from the planes without materialising that frame (the encoder
  * reads 1.5 instead of 4 bytes per pixel, twice).  Not in the reference.  Needs

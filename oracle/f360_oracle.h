@@ -111,6 +111,19 @@ void f360o_yuv420p_to_rgb0(uint8_t *dst, int dst_linesize, const uint8_t *y_plan
                            int y_linesize, const uint8_t *u_plane, int u_linesize,
                            const uint8_t *v_plane, int v_linesize, int width, int height,
                            int model);
+/* --- colour-space step behind the path (f360_oracle_rgb2yuv.c) ----------- */
+/* What sws_scale does for src/video_encoder.cc:380-395 (RGB0 -> yuv420p, same size): the
+ * generic scaler of FFmpeg 4.2, C functions (model F360O_YUV_SWS_C) or with the x86 vertical
+ * chroma scaler (F360O_YUV_SWS_X86).  Even width and height. */
+void f360o_rgb0_to_yuv420p(uint8_t *y_plane, int y_linesize, uint8_t *u_plane, int u_linesize,
+                           uint8_t *v_plane, int v_linesize, const uint8_t *src, int src_linesize,
+                           int width, int height, int model);
+/* the vertical chroma filter initFilter builds for that call: returns the filter size (taps
+ * per chroma row), fills filter_out[(height + 1) / 2][size] and pos_out[(height + 1) / 2] when
+ * size <= max_size */
+int f360o_rgb2yuv_chroma_vfilter(int16_t *filter_out, int32_t *pos_out, int height, int max_size);
+/* RY GY BY RU GU BU RV GV BV (utils.c:811-821) */
+void f360o_rgb2yuv_coeffs(int32_t *out9);
 
 /* --- "expand" debug views (f360_oracle_expand.c) --------------------------- */
 /* src/sat_decoder.cc:555-616 (== src/image_sampler.cc:358-419): reduced frame scattered back to

@@ -52,6 +52,10 @@ def lib() -> ctypes.CDLL:
         L.f360o_yuv_to_rgb_pixel.argtypes = [c_int, c_int, c_int, c_int, c_void_p]
         L.f360o_yuv420p_to_rgb0.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                             c_void_p, c_int, c_int, c_int, c_int]
+        L.f360o_rgb0_to_yuv420p.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                            c_void_p, c_int, c_int, c_int, c_int]
+        L.f360o_rgb2yuv_chroma_vfilter.argtypes = [c_void_p, c_void_p, c_int, c_int]
+        L.f360o_rgb2yuv_coeffs.argtypes = [c_void_p]
         L.f360o_is_grid.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
         L.f360o_is_sample_rect.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                            c_int, c_void_p, c_float, c_float]
@@ -187,6 +191,34 @@ def pipeline_encode_sample(frames, src_w, src_h, out_w, out_h, seed0):
     d = lib().f360o_pipeline_encode_sample(frames, src_w, src_h, out_w, out_h, seed0,
                                            ctypes.byref(sec))
     return int(d), sec.value
+
+
+def rgb0_to_yuv420p(rgb0, width, height, model, pads=(0, 0, 0)):
+    """rgb0: (height, linesize) uint8 rows of 4-byte pixels -> (y, u, v) planes (rows padded by
+    `pads` bytes, filled with 0xEE so that untouched bytes show)."""
+    rgb0 = np.ascontiguousarray(rgb0, dtype=np.uint8)
+    y = np.full((height, width + pads[0]), 0xEE, dtype=np.uint8)
+    u = np.full((height // 2, width // 2 + pads[1]), 0xEE, dtype=np.uint8)
+    v = np.full((height // 2, width // 2 + pads[2]), 0xEE, dtype=np.uint8)
+    lib().f360o_rgb0_to_yuv420p(_ptr(y), y.shape[1], _ptr(u), u.shape[1], _ptr(v), v.shape[1],
+                                _ptr(rgb0), rgb0.shape[1], width, height, model)
+    return y, u, v
+
+
+def rgb2yuv_chroma_vfilter(height):
+    """(filter[ch][size], pos[ch]) of libswscale's vertical chroma filter for RGB -> yuv420p."""
+    ch = (height + 1) // 2
+    f = np.zeros((ch, 8), dtype=np.int16)
+    p = np.zeros(ch, dtype=np.int32)
+    size = lib().f360o_rgb2yuv_chroma_vfilter(_ptr(f), _ptr(p), height, 8)
+    assert size <= 8
+    return f.reshape(-1)[:ch * size].reshape(ch, size).copy(), p
+
+
+def rgb2yuv_coeffs():
+    c = np.zeros(9, dtype=np.int32)
+    lib().f360o_rgb2yuv_coeffs(_ptr(c))
+    return [int(v) for v in c]
 
 
 def pipeline_compute(frames, first_index, src_w, src_h, out_w, out_h):

@@ -100,3 +100,70 @@ def test_host_constants_reproduce_both_converters(f360, oracle):
     # 32-bit arithmetic on the device: every intermediate fits
     for a in (base, base + (k["r0"] + ((V * k["crv"]) >> 16)) * k["cy"], yy, u * k["ubc"]):
         assert np.abs(a).max() < 2 ** 31
+
+
+# ------------------------------------------------------------------ output side: RGB0 -> yuv420p
+def frame_of(rgb, w, h):
+    fr = np.zeros((h, 4 * w), dtype=np.uint8)
+    fr.reshape(h, w, 4)[:, :, :3] = rgb
+    fr.reshape(h, w, 4)[:, :, 3] = 0x5A   # the pad byte must not matter
+    return fr
+
+
+def test_rgb2yuv_colour_bars_and_coefficients(oracle):
+    """ITU-R 601 limited range: the values every video engineer knows, from both models."""
+    assert oracle.rgb2yuv_coeffs() == [8414, 16519, 3208, -4865, -9528, 14392, 14392, -12061, -2332]
+    bars = {(255, 255, 255): (235, 128, 128), (0, 0, 0): (16, 128, 128), (255, 0, 0): (81, 90, 240),
+            (0, 255, 0): (145, 54, 34), (0, 0, 255): (41, 240, 110), (255, 255, 0): (210, 16, 146),
+            (0, 255, 255): (170, 166, 16), (255, 0, 255): (106, 202, 222)}
+    for model in (oracle.YUV_SWS_C, oracle.YUV_SWS_X86):
+        for rgb, want in bars.items():
+            y, u, v = oracle.rgb0_to_yuv420p(frame_of(rgb, 16, 8), 16, 8, model)
+            assert (y == want[0]).all() and (u == want[1]).all() and (v == want[2]).all(), (model, rgb)
+
+
+def test_rgb2yuv_vertical_chroma_filter_is_the_closed_form(oracle):
+    """initFilter restated as it stands (bilinear, 2:1, chroma sited between the two rows) gives
+    512 1536 1536 512 on rows 2c-1 .. 2c+2, folded at the frame borders -- the closed form the
+    device kernel uses."""
+    for h in list(range(8, 64, 2)) + [1080, 2144]:
+        f, p = oracle.rgb2yuv_chroma_vfilter(h)
+        ch = h // 2
+        assert f.shape == (ch, 4)
+        assert list(f[0]) == [2048, 1536, 512, 0] and p[0] == 0
+        assert list(f[-1]) == [0, 512, 1536, 2048] and p[-1] == h - 4
+        for c in range(1, ch - 1):
+            assert list(f[c]) == [512, 1536, 1536, 512] and p[c] == 2 * c - 1, (h, c)
+
+
+def test_rgb2yuv_luma_is_per_pixel_and_models_differ_by_at_most_one(oracle):
+    rng = np.random.default_rng(5)
+    w, h = 64, 24
+    fr = rng.integers(0, 256, (h, 4 * w), dtype=np.uint8)
+    yc, uc, vc = oracle.rgb0_to_yuv420p(fr, w, h, oracle.YUV_SWS_C)
+    yx, ux, vx = oracle.rgb0_to_yuv420p(fr, w, h, oracle.YUV_SWS_X86)
+    px = fr.reshape(h, w, 4).astype(np.int64)
+    y14 = (8414 * px[:, :, 0] + 16519 * px[:, :, 1] + 3208 * px[:, :, 2] + (32 << 14) + 256) >> 9
+    assert np.array_equal(yc, ((2 * y14 + 64) >> 7).astype(np.uint8)) and np.array_equal(yc, yx)
+    # chroma: the x86 scaler truncates each tap, never more than one code value below / above
+    assert np.abs(uc.astype(int) - ux.astype(int)).max() <= 1
+    assert np.abs(vc.astype(int) - vx.astype(int)).max() <= 1
+    assert np.array_equal(uc[-1], ux[-1]) and np.array_equal(vc[-1], vx[-1])   # last row: C both
+    # a vertically constant frame: chroma equals the one-row value whatever the taps
+    fr2 = np.tile(fr[:1], (h, 1))
+    _, u2, v2 = oracle.rgb0_to_yuv420p(fr2, w, h, oracle.YUV_SWS_C)
+    assert (u2 == u2[0]).all() and (v2 == v2[0]).all()
+
+
+def test_rgb2yuv_round_trip_through_the_input_side(oracle):
+    """yuv420p -> RGB0 (input side) -> yuv420p (output side) returns to the same planes up to
+    the rounding of two 8-bit conversions, on smooth content."""
+    w, h = 64, 32
+    yy, xx = np.mgrid[0:h, 0:w]
+    y = (40 + xx * 2 + yy).astype(np.uint8)
+    u = np.full((h // 2, w // 2), 118, dtype=np.uint8)
+    v = np.full((h // 2, w // 2), 140, dtype=np.uint8)
+    rgb = oracle.yuv420p_to_rgb0(y, u, v, w, h, oracle.YUV_SWS_C)
+    y2, u2, v2 = oracle.rgb0_to_yuv420p(rgb, w, h, oracle.YUV_SWS_C)
+    assert np.abs(y2.astype(int) - y.astype(int)).max() <= 2
+    assert np.abs(u2.astype(int) - 118).max() <= 2 and np.abs(v2.astype(int) - 140).max() <= 2

@@ -538,13 +538,15 @@ def replay_send_frame_loop(oracle, w, h, frames, client, trace, planar):
     return f"{oracle.fnv1a64(red):016x}", (cx, cy)
 
 
-def run_send_frame_loop(clients, fps, frames, w, h, trace_path, gpus, planar, timeout=300):
+def run_send_frame_loop(clients, fps, frames, w, h, trace_path, gpus, planar, timeout=300,
+                        planar_out=False):
     import json
     import subprocess
     repo = os.path.dirname(HERE)
     subprocess.run(["make", "-C", os.path.join(repo, "examples")], check=True, capture_output=True)
     cmd = [os.path.join(repo, "examples", "send_frame_loop_synth"), str(clients), str(fps),
-           str(frames), str(w), str(h), str(trace_path), str(gpus)] + (["yuv420p"] if planar else [])
+           str(frames), str(w), str(h), str(trace_path), str(gpus),
+           "yuv420p" if planar else "rgb0", "yuv420p" if planar_out else "rgb0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr
     return json.loads(out.stdout.strip().splitlines()[-1])
@@ -571,6 +573,28 @@ def test_send_frame_loop_example(f360, gpu_ctx, oracle, tmp_path, planar):
         if c == 0:
             assert np.array_equal(np.float32(res["client0_last_gaze"]), np.float32([cx, cy]))
             assert res["client0_last_digest"] == want
+
+
+def test_send_frame_loop_delivers_planes(f360, gpu_ctx, oracle, tmp_path):
+    """The loop with the output-side colour step on the device (1.5 bytes per pixel back over
+    PCIe): the delivered planes are the oracle's conversion of the replayed reduced frame."""
+    from test_gaze_trace import lissajous_trace, write_trace
+    trace = tmp_path / "gaze.txt"
+    points = lissajous_trace(64)
+    write_trace(trace, points, junk=False)
+    w, h, frames = 640, 320, 7
+    res = run_send_frame_loop(1, 120, frames, w, h, trace, 1, False, planar_out=True)
+    assert res["delivered"] == "yuv420p"
+    rw, rh = reduced(w), reduced(h)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    red = np.zeros((rh, 4 * rw), dtype=np.uint8)
+    for k in range(frames):
+        cx, cy = [np.float32(v) for v in points[k % len(points)][3:5]]
+        sat = oracle.sat_encode(oracle.lcg_frame(w, h, 12345 + k % 3), w, h, 4 * w)
+        oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, grid, float(cx), float(cy))
+    y, u, v = oracle.rgb0_to_yuv420p(red, rw, rh, oracle.YUV_SWS_X86)
+    planes = np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)])
+    assert res["last_digests"][0] == f"{oracle.fnv1a64(planes):016x}"
 
 
 def test_send_frame_loop_config5_8k(f360, gpu_ctx, oracle, tmp_path):
@@ -992,6 +1016,44 @@ def test_fused_foveation_from_yuv420p(f360, gpu_ctx, oracle, w, h):
     for b in (dy, du, dv, dst):
         b.free()
     dec.close()
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("w,h,spad,pads,off", [(64, 32, 0, (0, 0, 0), 0), (4272, 2144, 0, (0, 0, 0), 0),
+                                                (72, 16, 16, (8, 4, 12), 0), (70, 10, 4, (1, 3, 5), 0),
+                                                (64, 8, 0, (0, 0, 0), 4), (2, 8, 0, (0, 0, 0), 0)])
+def test_rgb0_to_yuv420p_matches_oracle(f360, gpu_ctx, oracle, model, w, h, spad, pads, off):
+    """The output-side colour step (VideoEncoder's sws_scale, video_encoder.cc:380-395) on the
+    device: both libswscale models, the 8-pixel vector kernel and the any-even-width kernel
+    (odd multiples of two, padded rows, unaligned base), bytes outside the planes untouched."""
+    rng = np.random.default_rng(17)
+    src_h = rng.integers(0, 256, (h, 4 * w + spad), dtype=np.uint8)
+    want = oracle.rgb0_to_yuv420p(src_h, w, h, model, pads=pads)
+    gpu_ctx.set_option("yuv.model", model)
+    raw = np.zeros(src_h.size + 64, dtype=np.uint8)
+    raw[off:off + src_h.size] = src_h.reshape(-1)
+    src = gpu_ctx.upload(raw)
+    planes = [gpu_ctx.malloc(p.size) for p in want]
+    for p in planes:
+        p.fill(0xEE)
+    gpu_ctx.rgb0_to_yuv420p(planes[0].ptr, planes[1].ptr, planes[2].ptr, want[0].shape[1],
+                            want[1].shape[1], want[2].shape[1], src.ptr + off, src_h.shape[1], w, h)
+    for name, buf, ref in zip("yuv", planes, want):
+        got = buf.copy_to_host(np.uint8, ref.shape)
+        assert np.array_equal(got, ref), (name, int((got != ref).sum()))
+        buf.free()
+    src.free()
+    gpu_ctx.set_option("yuv.model", 1)
+
+
+def test_rgb0_to_yuv420p_argument_checks(f360, gpu_ctx):
+    a = gpu_ctx.malloc(1 << 16)
+    for (w, h) in [(63, 32), (64, 31), (64, 6), (0, 8)]:
+        with pytest.raises(f360.F360Error):
+            gpu_ctx.rgb0_to_yuv420p(a.ptr, a.ptr, a.ptr, 64, 32, 32, a.ptr, 256, w, h)
+    with pytest.raises(f360.F360Error):   # chroma linesize below width / 2
+        gpu_ctx.rgb0_to_yuv420p(a.ptr, a.ptr, a.ptr, 64, 16, 32, a.ptr, 256, 64, 32)
+    a.free()
 
 
 def test_yuv_argument_checks(f360, gpu_ctx):
