@@ -181,7 +181,14 @@ __device__ __forceinline__ int2 chroma15(const Rgb2YuvConsts &k, uint32_t p0, ui
   const int v14 = (k.rv * r + k.gv * g + k.bv * b + (256 << 15) + (1 << 9)) >> 10;
   return make_int2(min(2 * u14, 32767), min(2 * v14, 32767));
 }
-__device__ __forceinline__ uint32_t clip8(int v) { return (uint32_t)min(max(v, 0), 255); }
+// clamp(v >> N, 0, 255), written as clamp-then-shift: hipcc 7.2 folds two adjacent
+// clamp(x >> n, 0, 255) into v_ashr_pk_u8_i32 and then ORs further bytes into that register as
+// if its upper half were zero, which on gfx950 it is not (the parity test found it, as it did in
+// yuv_device.h in round 1); this form does not match the pattern
+template <int N>
+__device__ __forceinline__ uint32_t shift_clip8(int v) {
+  return (uint32_t)(min(max(v, 0), (256 << N) - 1) >> N);
+}
 
 // A thread owns PAIRS chroma samples of one chroma row: 2 * PAIRS pixels of the four source
 // rows its vertical filter needs, the luma of the two rows it is centred on.  PAIRS = 4: 32-byte
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256) void rgb0_to_yuv420p_kernel(
       uint32_t w[(PAIRS + 1) / 2];
 #pragma unroll
       for (int q = 0; q < 2 * PAIRS; ++q) {
-        const uint32_t yv = clip8((luma15(k, px[q]) + 64) >> 7);
+        const uint32_t yv = shift_clip8<7>(luma15(k, px[q]) + 64);
         if ((q & 3) == 0) w[q >> 2] = yv;
         else w[q >> 2] |= yv << (8 * (q & 3));
       }
@@ -263,8 +270,8 @@ __global__ __launch_bounds__(256) void rgb0_to_yuv420p_kernel(
   uint32_t ub = 0, vb = 0;
 #pragma unroll
   for (int q = 0; q < PAIRS; ++q) {
-    ub |= clip8(mmx ? acc_u[q] >> 3 : acc_u[q] >> 19) << (8 * q);
-    vb |= clip8(mmx ? acc_v[q] >> 3 : acc_v[q] >> 19) << (8 * q);
+    ub |= (mmx ? shift_clip8<3>(acc_u[q]) : shift_clip8<19>(acc_u[q])) << (8 * q);
+    vb |= (mmx ? shift_clip8<3>(acc_v[q]) : shift_clip8<19>(acc_v[q])) << (8 * q);
   }
   uint8_t *yo0 = y_dst + (size_t)(2 * cy) * y_linesize + (size_t)c0 * 2;
   uint8_t *yo1 = yo0 + y_linesize;

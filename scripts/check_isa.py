@@ -11,7 +11,8 @@ bump that re-serialises one of their inner loops would still pass every parity t
     sat_reduce_kernel has no row-batch loop left that waits with counted vmcnt only;
   * a table store of sat_write_kernel lost its `nt` bit;
   * the row loop of sample_rect_stream_kernel lost its LDS-direct loads, waits with vmcnt(0), or
-    no longer waits with a counted vmcnt at all.
+    no longer waits with a counted vmcnt at all;
+  * any kernel contains v_ashr_pk_u8_i32 (hipcc 7.2 packs bytes wrongly around it).
 
     python scripts/check_isa.py [path/to/libf360.so]        (exit 0 = all rules hold)
 """
@@ -98,6 +99,11 @@ def main():
                               not any(t.startswith("s_waitcnt vmcnt(0)") for t in lt)]
                     if not steady:
                         problems.append(f"{name}: no row-batch loop with counted waits only")
+                # hipcc 7.2 miscompiles byte packing around this instruction (its upper half is
+                # not zero on gfx950 but later ORs assume so): both times it appeared, the parity
+                # tests failed; the kernels are written so that it is not selected
+                if any(t.startswith("v_ashr_pk_u8_i32") for t in texts):
+                    problems.append(f"{name}: v_ashr_pk_u8_i32 selected (known-bad byte packing)")
                 if "sample_rect_stream_kernel" in name:
                     seen.add("streamer")
                     row_loops = [[t for _, t, _ in lp] for lp in loops(ins)

@@ -1040,7 +1040,9 @@ def test_rgb0_to_yuv420p_matches_oracle(f360, gpu_ctx, oracle, model, w, h, spad
                             want[1].shape[1], want[2].shape[1], src.ptr + off, src_h.shape[1], w, h)
     for name, buf, ref in zip("yuv", planes, want):
         got = buf.copy_to_host(np.uint8, ref.shape)
-        assert np.array_equal(got, ref), (name, int((got != ref).sum()))
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, (name, len(bad), bad[:6].tolist(), got[got != ref][:6].tolist(),
+                               ref[got != ref][:6].tolist())
         buf.free()
     src.free()
     gpu_ctx.set_option("yuv.model", 1)
