@@ -156,6 +156,14 @@ __device__ __noinline__ float2 logpolar_uv_outlined(int dx, int dy, int rw, int 
 // Hence a table over the offsets, built once per geometry and shared by every gaze:
 // uv[(dy + span_y) * pitch + (dx + span_x)], |dx| <= span_x = W/2 + 1, |dy| <= span_y = H
 // (every offset a gaze inside the frame can produce; others are computed directly).
+//
+// Measured against this layout in round 2 and not kept (A/B on one box, 8K, this kernel's
+// ~150 instructions per pixel and the way its loads batch across the four rows decide its time,
+// not the table's bytes): a one-quadrant table of { i_f, atan(|dy| / |dx|) } with j_f rebuilt
+// from the signs (118 instead of 472 MB; 151 -> 174 us); a flag in i_f's spare sign bit for
+// "the exact-hit test cannot pass at this offset" (true for four pixels in five) that skips the
+// radius / cos / sin loads (151 -> 178 us: loads inside a branch stop the compiler from
+// batching them) or only the double arithmetic (151 -> 192 us).
 struct LogpolarTable {
   const float2 *uv;
   int span_x, span_y, pitch;

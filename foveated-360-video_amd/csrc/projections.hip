@@ -21,10 +21,29 @@ __device__ __forceinline__ float cr_atan2f(float y, float x) {
   return (float)atan2((double)y, (double)x);
 }
 
+// fmod(x, 2 pi), exactly, without the library's iterative remainder loop wherever x lies in
+// [8 pi, 14 pi) -- which is where the kernel's two calls (phi + pi/2 + 10 pi and
+// lambda + pi + 10 pi, projections_program.cl:36-37) land for any gaze inside the frame; a gaze
+// far outside it takes the library routine.  fmod returns x - n y with n = trunc(x / y), which
+// is representable; in the window n is 4, 5 or 6, and every step below is a Sterbenz
+// subtraction (operands within a factor of two of each other, hence exact): x - 4y (4y is a power-of-two multiple of y), then - 2y or
+// - y as long as the remainder allows.
+__device__ __forceinline__ double fmod_two_pi_window(double x) {
+  const double y = 2 * F360_PI;
+  if (!(x >= 4.0 * y && x < 7.0 * y)) return fmod(x, y);
+  double a = x - 4.0 * y;
+  if (a >= 2.0 * y) a -= 2.0 * y;
+  if (a >= y) a -= y;
+  return a;
+}
+
 // What the kernel computes from the target pixel alone (:21-24,29-30 and the sin / cos of c in
 // :31-34): screen coordinates, rho, sin(atan(rho)), cos(atan(rho)).  Three of the five
 // transcendentals per pixel do not depend on the view centre, so they are tabulated once per
-// target geometry ("gnomonic.table") with this very code and read back every frame.
+// target geometry ("gnomonic.table") with this very code and read back every frame.  (All five
+// values are stored: with x, y and rho recomputed -- two correctly rounded divisions and a
+// square root -- and only sc, cc read back, the kernel is slower, 59 -> 66 us for a 3840x1920
+// viewport; it is bound by instructions, the double asin and atan2 above all, not by bytes.)
 struct GnomonicPixel {
   float x, y, rho, sc, cc;
 };
@@ -75,8 +94,8 @@ __global__ __launch_bounds__(256) void gnomonic_kernel(
   const float x = p.x, y = p.y, rho = p.rho, sc = p.sc, cc = p.cc;
   float phi = cr_asinf(cc * sp1 + (y * sc * cp1) / rho);
   float lam = lambda0 + cr_atan2f(x * sc, rho * cp1 * cc - y * sp1 * sc);
-  phi = (float)fmod((double)phi + F360_PI_2 + 10 * F360_PI, 2 * F360_PI);
-  lam = (float)fmod((double)lam + F360_PI + 10 * F360_PI, 2 * F360_PI);
+  phi = (float)fmod_two_pi_window((double)phi + F360_PI_2 + 10 * F360_PI);
+  lam = (float)fmod_two_pi_window((double)lam + F360_PI + 10 * F360_PI);
   float su = (float)((double)lam / (2.0 * F360_PI));
   float sv = (float)((double)phi / (F360_PI));
   // clamp() = fmin(fmax(x, lo), hi): the NaN of the exact viewport centre
