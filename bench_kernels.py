@@ -60,6 +60,12 @@ def main():
             ("foveate_rect from yuv420p", w * h * 3 // 2 + 4 * rw * rh,
              lambda k: dec.FoveateFrameRectYUV420PGPU(red.ptr, rw, rh, 4 * rw, *yuv_args(k), w, h,
                                                       0.4 + 0.01 * k, 0.5)),
+            ("rgb0_to_yuv420p (reduced frame)", 4 * rw * rh + rw * rh * 3 // 2,
+             lambda k: ctx.rgb0_to_yuv420p(oy.ptr, ou.ptr, ov.ptr, rw, rw // 2, rw // 2, red.ptr,
+                                           4 * rw, rw, rh)),
+            ("rgb0_to_yuv420p (full frame)", 4 * w * h + w * h * 3 // 2,
+             lambda k: ctx.rgb0_to_yuv420p(fy.ptr, fu.ptr, fv.ptr, w, w // 2, w // 2,
+                                           frames[k % nbuf].ptr, 4 * w, w, h)),
             ("sample_rect (SAT)", 12 * (rw + 1) * (rh + 1) + 4 * rw * rh,
              lambda k: dec.SampleFrameRectGPU(red.ptr, rw, rh, 4 * rw, sat.ptr, (w, h), 0.4 + 0.01 * k, 0.5)),
             ("interpolate_rect", 4 * rw * rh + 4 * w * h,
@@ -77,6 +83,8 @@ def main():
             ("gnomonic (to w/2 x h/2)", 8 * (w // 2) * (h // 2),
              lambda k: proj.GnomonicProjection(view.ptr, w // 2, h // 2, 2 * w, frames[k % nbuf].ptr, w, h, 4 * w, 0.5, 0.5)),
         ]
+        oy, ou, ov = ctx.malloc(rw * rh), ctx.malloc(rw * rh // 4), ctx.malloc(rw * rh // 4)
+        fy, fu, fv = ctx.malloc(w * h), ctx.malloc(w * h // 4), ctx.malloc(w * h // 4)
         e0, e1 = f360.Event(ctx), f360.Event(ctx)
         out = []
         for name, nbytes, fn in cases:

@@ -34,8 +34,10 @@ def means(path, counter):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
+            # keep the template arguments: the benchmark's after-run variants launch other
+            # instantiations of the same kernels (emit mode, planar sources)
             name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-            acc.setdefault(name.split("<")[0], []).append(float(row["Counter_Value"]))
+            acc.setdefault(name.strip(), []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -52,15 +54,23 @@ def main():
                      "(confirmed on the reducer: 57.7 MB reported for a 118 MB frame); WRITE_SIZE as "
                      "is.  bench.py uses it only while csrc_sha equals the hash of its own csrc/."),
            "csrc_sha": csrc_hash()}
-    for kernel, dbl in (("sat_write_kernel", 2), ("sat_reduce_kernel", 2), ("sat_carry_kernel", 2),
-                        ("sample_rect_stream_kernel", 2), ("sample_rect_walk_kernel", 1)):
-        if kernel in fetch and kernel in write:
-            doc[kernel] = {size: int(1024 * (dbl * fetch[kernel] + write[kernel]))}
+    # (instantiation measured, key in the file, FETCH_SIZE factor): RGB0 source = 1, table
+    # writer with LDS-staged stores = 1; tile streamer with a ring of 3 slots, byte stores
+    for inst, kernel, dbl in (("sat_write_kernel<1, 1>", "sat_write_kernel", 2),
+                              ("sat_reduce_kernel<1>", "sat_reduce_kernel", 2),
+                              ("sat_carry_kernel", "sat_carry_kernel", 2),
+                              ("sample_rect_stream_kernel<3, false>", "sample_rect_kernel", 2)):
+        if inst in fetch and inst in write:
+            doc[kernel] = {size: int(1024 * (dbl * fetch[inst] + write[inst])),
+                           "_fetch_kb": round(fetch[inst], 1), "_write_kb": round(write[inst], 1),
+                           "_instance": inst}
     if len(sys.argv) >= 6:
         yf, yw = means(sys.argv[4], "FETCH_SIZE"), means(sys.argv[5], "WRITE_SIZE")
-        for kernel in ("sat_write_kernel", "sat_reduce_kernel"):
-            if kernel in yf and kernel in yw:
-                doc.setdefault(kernel, {})[size + ":yuv420p"] = int(1024 * (2 * yf[kernel] + yw[kernel]))
+        # planar source, x86 rounding model = 3
+        for inst, kernel in (("sat_write_kernel<3, 1>", "sat_write_kernel"),
+                             ("sat_reduce_kernel<3>", "sat_reduce_kernel")):
+            if inst in yf and inst in yw:
+                doc.setdefault(kernel, {})[size + ":yuv420p"] = int(1024 * (2 * yf[inst] + yw[inst]))
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc))
