@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """bench_configs.py -- the BASELINE.json configs that are not the headline benchmark (bench.py).
 
-    python tests/bench_configs.py [--config 2|3|5|all] [--quick]
+    python tests/bench_configs.py [--config 2|3|4|5|all] [--quick]
 
 (It lives under tests/ because it uses the CPU oracle as the parity checker of configs 2 and 3.)
 
 config 2  300 frames 1920x1080 (LCG seeds 1..300, Lissajous gaze): SAT encode + SAT sample_rect on
           1 GPU; every frame's SAT and reduced frame is then compared with the oracle (digests).
+config 4  7680x3840, the batch SURVEY 8(d)-4 describes: 64 LCG frames (seeds 1..64) plus one all-255
+          frame (the table wraps mod 2^32), Lissajous gaze, SAT encode + sample_rect; digest parity
+          of the table and the reduced frame on EVERY frame, full compare on two.  (Throughput
+          of this config is bench.py's job; here the frames go one at a time.)
 config 3  3840x1920: log-polar forward warp + bilinear inverse over the 17x9 gaze lattice; a few
           gaze points are compared with the oracle (+-1 per 8-bit channel).
 config 5  8K streaming loop at 60 fps with 8 gaze clients (examples/send_frame_loop_synth, the
@@ -77,6 +81,54 @@ def config2(f360, ob, quick):
             "mpix_per_s": round(n * w * h / 1e6 / dt, 1), "us_per_frame": round(1e6 * dt / n, 2),
             "hbm_frac_algorithmic": round((enc_b + smp_b) * n / dt / 8e12, 4),
             "parity": f"{n - bad}/{n} frames SAT and reduced frame bit-exact vs oracle"}
+
+
+def config4_frames(ob, indices, w, h):
+    """Frame k of config 4: LCG seed k + 1 for k < 64, the all-255 frame for k == 64."""
+    for k in indices:
+        yield k, (np.full((h, 4 * w), 255, dtype=np.uint8) if k == 64 else ob.lcg_frame(w, h, 1 + k))
+
+
+def config4(f360, ob, quick, indices=None):
+    w, h = 7680, 3840
+    rw, rh = reduced(w), reduced(h)
+    if indices is None:
+        indices = list(range(8)) + [64] if quick else list(range(65))
+    grid = ob.satdec_grid(rw, rh, w, h)
+    bad, full_compared, t_gpu = [], 0, 0.0
+    with f360.Context(0) as ctx:
+        enc, dec = f360.SATEncoder(ctx), f360.SATDecoder(ctx)
+        dec.InitializeGrid(rw, rh, w, h)
+        src, sat, red = ctx.malloc(4 * w * h), ctx.malloc(12 * w * h), ctx.malloc(4 * rw * rh)
+        for k, frame in config4_frames(ob, indices, w, h):
+            cx, cy = lissajous(k)
+            src.copy_from_host(frame.reshape(-1))
+            red.fill(0)
+            ctx.finish()
+            t0 = time.perf_counter()
+            enc.EncodeFrameGPU(sat.ptr, src.ptr, w, h, 4 * w)
+            dec.SampleFrameRectGPU(red.ptr, rw, rh, 4 * rw, sat.ptr, (w, h), cx, cy)
+            ctx.finish()
+            t_gpu += time.perf_counter() - t0
+            got_sat = sat.copy_to_host(np.uint32, (h, w, 3))
+            got_red = red.copy_to_host(np.uint8, (rh, 4 * rw))
+            want_sat = ob.sat_encode(frame, w, h, 4 * w)
+            want_red = ob.satdec_sample_rect(np.zeros((rh, 4 * rw), dtype=np.uint8), rw, rh, 4 * rw,
+                                             want_sat, w, h, grid, cx, cy)
+            ok = (ob.fnv1a64(got_sat) == ob.fnv1a64(want_sat)
+                  and ob.fnv1a64(got_red) == ob.fnv1a64(want_red))
+            if k in (indices[0], indices[-1]):  # full compare on two, the wrapped one among them
+                ok = ok and np.array_equal(got_sat, want_sat) and np.array_equal(got_red, want_red)
+                full_compared += 1
+            if not ok:
+                bad.append(k)
+        dec.close()
+    n = len(indices)
+    return {"config": 4, "workload": f"{n} frames {w}x{h} (LCG seeds, + all-255), SAT encode + "
+                                     f"sample_rect to {rw}x{rh}, Lissajous gaze, one at a time",
+            "us_per_frame_unbatched": round(1e6 * t_gpu / n, 1), "bad_frames": bad,
+            "parity": f"{n - len(bad)}/{n} frames: table and reduced frame digests equal the "
+                      f"oracle's; {full_compared} compared in full"}
 
 
 def config3(f360, ob, quick):
@@ -155,10 +207,10 @@ def main():
     import oracle_binding as ob
     if f360.device_count() < 1:
         sys.exit("bench_configs.py: no HIP device visible; there is no CPU fallback")
-    todo = ["2", "3", "5"] if args.config == "all" else [args.config]
+    todo = ["2", "3", "4", "5"] if args.config == "all" else [args.config]
     for c in todo:
         res = config2(f360, ob, args.quick) if c == "2" else config3(f360, ob, args.quick) if c == "3" \
-            else config5(args.quick)
+            else config4(f360, ob, args.quick) if c == "4" else config5(args.quick)
         for r in (res if isinstance(res, list) else [res]):
             print(json.dumps(r), flush=True)
 
