@@ -68,6 +68,9 @@ def main():
                                            frames[k % nbuf].ptr, 4 * w, w, h)),
             ("sample_rect (SAT)", 12 * (rw + 1) * (rh + 1) + 4 * rw * rh,
              lambda k: dec.SampleFrameRectGPU(red.ptr, rw, rh, 4 * rw, sat.ptr, (w, h), 0.4 + 0.01 * k, 0.5)),
+            ("sample_rect, 8 gaze points against one table (per gaze)", 12 * (rw + 1) * (rh + 1) + 4 * rw * rh,
+             lambda k: dec.SampleFrameRectGPUBatch([r.ptr for r in reds8], rw, rh, 4 * rw, sat.ptr, (w, h),
+                                                   [(0.3 + 0.05 * c + 0.01 * k, 0.5) for c in range(8)])),
             ("interpolate_rect", 4 * rw * rh + 4 * w * h,
              lambda k: dec.InterpolateFrameRectGPU(full.ptr, w, h, 4 * w, red.ptr, rw, rh, 4 * rw, 0.4 + 0.01 * k, 0.5)),
             ("decode (SAT -> RGB0)", 12 * w * h + 4 * w * h,
@@ -83,6 +86,7 @@ def main():
             ("gnomonic (to w/2 x h/2)", 8 * (w // 2) * (h // 2),
              lambda k: proj.GnomonicProjection(view.ptr, w // 2, h // 2, 2 * w, frames[k % nbuf].ptr, w, h, 4 * w, 0.5, 0.5)),
         ]
+        reds8 = [ctx.malloc(4 * rw * rh) for _ in range(8)]
         oy, ou, ov = ctx.malloc(rw * rh), ctx.malloc(rw * rh // 4), ctx.malloc(rw * rh // 4)
         fy, fu, fv = ctx.malloc(w * h), ctx.malloc(w * h // 4), ctx.malloc(w * h // 4)
         e0, e1 = f360.Event(ctx), f360.Event(ctx)
@@ -95,6 +99,8 @@ def main():
                 fn(k)
             e1.record()
             us = 1e3 * e0.elapsed_ms(e1) / args.reps
+            if "(per gaze)" in name:
+                us /= 8
             out.append({"kernel": name, "us": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 1),
                         "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4)})
         print(json.dumps({"frame": [w, h], "reduced": [rw, rh], "reps": args.reps, "kernels": out}))

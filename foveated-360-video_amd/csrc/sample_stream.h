@@ -448,3 +448,4 @@ __global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArg
   tile_stream_body<NS, GROUPS>(a, t, blk * rows, rows,
                    (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]), &stage[wave][0]);
 }
+

@@ -278,6 +278,62 @@ __device__ __forceinline__ uint32_t lds_load4(uint32_t addr) {
 
 #include "sample_stream.h"
 
+template <int NS>
+__global__ __launch_bounds__(256) void sample_rect_stream_batch_kernel(SampleArgs a,
+                                                                        const SampleBatch b,
+                                                                        int rows, int nblocks) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[4][NS * ts_slot_bytes(false) + kTsStageBytes];
+  const int wave = threadIdx.x >> 6;
+  const int z = blockIdx.y;
+  a.dst = b.dst[z];
+  a.cxp = b.cxp[z];
+  a.cyp = b.cyp[z];
+  const int ntiles = (a.src_w + kTsTile - 1) / kTsTile;
+  const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+  if (g >= ntiles * nblocks) return;
+  const int blk = g / ntiles;
+  tile_stream_body<NS, false>(a, g - blk * ntiles, blk * rows, rows,
+                              (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]),
+                              &stage[wave][0]);
+}
+
+// Host check of what tile_stream_body assumes for a gaze: per 128-texel tile the largest of the
+// candidate ranges fits two passes (128 pixels) and the others together one (64).
+bool tile_stream_fits(const f360_sat_decoder *dec, int cxp, int source_width, int target_width) {
+  const int ntiles = (source_width + kTsTile - 1) / kTsTile;
+  const std::vector<int> &lb = dec->lbx_host;
+  auto lb_at = [&](long d) {
+    return lb[(size_t)std::min<long>(std::max<long>(d - dec->lb_dmin, 0), (long)lb.size() - 1)];
+  };
+  for (int t = 0; t < ntiles; ++t) {
+    int largest = 0, total = 0;
+    for (int q = 0; q < kTsRanges; ++q) {
+      const int k = (q == 1 || q == 4) ? 1 : (q == 2 ? -1 : 0);
+      long lo_b = (long)t * kTsTile + (long)k * source_width - cxp, hi_b = lo_b + kTsTile;
+      if (q >= 3) {
+        lo_b = hi_b;
+        hi_b = lo_b + (t == ntiles - 1 ? dec->halo : 0);
+      }
+      const int i_lo = std::max(lb_at(lo_b) - 1, 0);
+      const int i_hi = std::max(std::min(lb_at(hi_b) - 1, target_width), i_lo);
+      largest = std::max(largest, i_hi - i_lo);
+      total += i_hi - i_lo;
+    }
+    if (largest > kTsTile || total - largest > 64) return false;
+  }
+  return true;
+}
+// ... and of the call as a whole: the per-geometry tables (inverse grid, halo) belong to the
+// source size the grid was initialised for; any other size takes the walker
+bool tile_stream_applies(const f360_sat_decoder *dec, const uint32_t *sat_dev, int source_width,
+                         int source_height, int target_linesize, int target_height) {
+  return dec->stream_ok && (source_width % 4) == 0 && source_width == dec->sw &&
+         source_height == dec->sh &&
+         (size_t)source_width * source_height * 12 < ((size_t)1 << 32) &&
+         (size_t)target_linesize * target_height < ((size_t)1 << 32) &&
+         ((uintptr_t)sat_dev % 16) == 0 && source_height <= 0xffff && target_height < 0xffff;
+}
+
 // ---------------------------------------------------------------------------
 // Fused foveation (SURVEY.md 8f-1 i): frame -> reduced frame without materialising the table.
 // When the gaze is known before the encode (the offline modes of the reference take it from a
@@ -859,41 +915,13 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   sa.ablate = ctx->opt_ablate;
   sa.reverse = ctx->opt_sample_reverse;
   const int variant = ctx->opt_sample_variant;
-  // the tile streamer's per-geometry tables (inverse grid, halo) belong to the source size the
-  // grid was initialised for; any other size takes the walker
-  const bool can_stream = dec->stream_ok && (source_width % 4) == 0 &&
-                          source_width == dec->sw && source_height == dec->sh &&
-                          (size_t)source_width * source_height * 12 < ((size_t)1 << 32) &&
-                          (size_t)target_linesize * target_height < ((size_t)1 << 32) &&
-                          ((uintptr_t)sat_dev % 16) == 0 && source_height <= 0xffff &&
-                          target_height < 0xffff;
+  const bool can_stream = tile_stream_applies(dec, sat_dev, source_width, source_height,
+                                              target_linesize, target_height);
   f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
   bool streamed = false;
   if (variant == 2 && can_stream) {
-    // the kernel's candidate ranges per 128-texel tile for THIS gaze: the largest must fit two
-    // passes (128 pixels), the others together one (64)
     const int ntiles = (source_width + kTsTile - 1) / kTsTile;
-    const std::vector<int> &lb = dec->lbx_host;
-    auto lb_at = [&](long d) {
-      return lb[(size_t)std::min<long>(std::max<long>(d - dec->lb_dmin, 0), (long)lb.size() - 1)];
-    };
-    bool fits = true;
-    for (int t = 0; t < ntiles && fits; ++t) {
-      int largest = 0, total = 0;
-      for (int q = 0; q < kTsRanges; ++q) {
-        const int k = (q == 1 || q == 4) ? 1 : (q == 2 ? -1 : 0);
-        long lo_b = (long)t * kTsTile + (long)k * source_width - cxp, hi_b = lo_b + kTsTile;
-        if (q >= 3) {
-          lo_b = hi_b;
-          hi_b = lo_b + (t == ntiles - 1 ? dec->halo : 0);
-        }
-        const int i_lo = std::max(lb_at(lo_b) - 1, 0);
-        const int i_hi = std::max(std::min(lb_at(hi_b) - 1, target_width), i_lo);
-        largest = std::max(largest, i_hi - i_lo);
-        total += i_hi - i_lo;
-      }
-      fits = largest <= kTsTile && total - largest <= 64;
-    }
+    const bool fits = tile_stream_fits(dec, cxp, source_width, target_width);
     if (fits) {
       const int rows = std::min(ctx->opt_stream_rows, kTsMaxRows);
       const int nblocks = (target_height + rows - 1) / rows;
@@ -978,13 +1006,40 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
   sa.src_h = source_height;
   sa.gx = dec->gx_dev.as<int16_t>();
   sa.gy = dec->gy_dev.as<int16_t>();
+  sa.lbx = dec->lbx_dev.as<int>();
+  sa.lb_dmin = dec->lb_dmin;
+  sa.lb_n = dec->lb_n;
+  sa.halo = dec->halo;
   f360_ctx *ctx = dec->ctx;
-  const int rows = ctx->opt_walk_rows;
-  const dim3 grid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),
-                  (target_height + rows - 1) / rows, count);
+  sa.ablate = ctx->opt_ablate;
   f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
-  hipLaunchKernelGGL(sample_rect_walk_batch_kernel, grid, dim3(256), 0, ctx->stream, sa, b,
-                     rows);
+  // the tile streamer when every client's gaze passes its host checks, else the walker for all
+  bool stream = ctx->opt_sample_variant == 2 &&
+                tile_stream_applies(dec, sat_dev, source_width, source_height, target_linesize,
+                                    target_height);
+  for (int k = 0; k < count && stream; ++k)
+    stream = tile_stream_fits(dec, b.cxp[k], source_width, target_width);
+  if (stream) {
+    const int ntiles = (source_width + kTsTile - 1) / kTsTile;
+    const int rows = std::min(ctx->opt_stream_rows, kTsMaxRows);
+    const int nblocks = (target_height + rows - 1) / rows;
+    const dim3 sgrid((unsigned)((ntiles * nblocks + 3) / 4), (unsigned)count);
+    if (ctx->opt_stream_depth <= 2)
+      hipLaunchKernelGGL(sample_rect_stream_batch_kernel<3>, sgrid, dim3(256), 0, ctx->stream, sa,
+                         b, rows, nblocks);
+    else if (ctx->opt_stream_depth <= 3)
+      hipLaunchKernelGGL(sample_rect_stream_batch_kernel<4>, sgrid, dim3(256), 0, ctx->stream, sa,
+                         b, rows, nblocks);
+    else
+      hipLaunchKernelGGL(sample_rect_stream_batch_kernel<6>, sgrid, dim3(256), 0, ctx->stream, sa,
+                         b, rows, nblocks);
+  } else {
+    const int rows = ctx->opt_walk_rows;
+    const dim3 grid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),
+                    (target_height + rows - 1) / rows, count);
+    hipLaunchKernelGGL(sample_rect_walk_batch_kernel, grid, dim3(256), 0, ctx->stream, sa, b,
+                       rows);
+  }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

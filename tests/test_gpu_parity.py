@@ -490,8 +490,11 @@ def test_cpp_dropin_example(f360, gpu_ctx, oracle):
 
 
 # ------------------------------------------------------------ next rows of SURVEY.md 8(f)
-def test_sample_rect_batch_matches_oracle(f360, gpu_ctx, oracle):
-    """8(f)-1: several gaze points against one table in one launch."""
+@pytest.mark.parametrize("variant", [1, 2])
+def test_sample_rect_batch_matches_oracle(f360, gpu_ctx, oracle, variant):
+    """8(f)-1: several gaze points against one table in one launch -- by the tile streamer when
+    every gaze passes its host checks (variant 2, the default), else by the walker."""
+    gpu_ctx.set_option("sample.variant", variant)
     w, h = 1920, 1080
     rw, rh = reduced(w), reduced(h)
     frame = oracle.lcg_frame(w, h, 31)
@@ -512,6 +515,7 @@ def test_sample_rect_batch_matches_oracle(f360, gpu_ctx, oracle):
         o.free()
     with pytest.raises(f360.F360Error):
         dec.SampleFrameRectGPUBatch([1] * 17, rw, rh, 4 * rw, sat.ptr, (w, h), [(0.5, 0.5)] * 17)
+    gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
     sat.free()
     dec.close()
 
