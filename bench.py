@@ -142,6 +142,12 @@ def main():
                          "blocks (BASELINE config 4: 64 -> 8 per GPU at N = 8); overrides --batch")
     ap.add_argument("--dry-run", action="store_true",
                     help="print the launch command and the per-rank frame ranges; no GPU call")
+    ap.add_argument("--frames-per-call", type=int, default=8,
+                    help="two-call path, RGB0 source: N frames per EncodeFramesGPU call, then one "
+                         "SampleFramesRectGPU call for their N tables (the frames share launches: "
+                         "the encoder as many as stay cache-resident between its two reads -- one "
+                         "at 8K --, the sampler all N); 1 = EncodeFrameGPU + SampleFrameRectGPU "
+                         "per frame, the reference's own loop")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (in-order streams) per GPU; frames go round-robin over them "
                          "(3 gives ~15%% more throughput; 1 keeps every kernel launch comparable with "
@@ -242,7 +248,10 @@ def main():
     decs = [f360.SATDecoder(c) for c in ctxs]
     for d in decs:
         d.InitializeGrid(rw, rh, w, h)
-    sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev) for _ in ctxs]
+    # (several streams: frames go round-robin over the contexts one call pair at a time)
+    fpc = 1 if (args.fused or yuv or nstreams > 1) else max(1, min(args.frames_per_call, B))
+    sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev)
+            for _ in range(max(len(ctxs), fpc))]
     reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
     gazes = [lissajous(g) for g in mine]
     if yuv:
@@ -254,7 +263,24 @@ def main():
     sat_ptr = [s.data_ptr() for s in sats]
     torch.cuda.synchronize(dev)
 
+    calls = [0]
+
+    def step_batched(profile):
+        # frames [g, g + n) in one encode call and one sample call; every profile_every-th
+        # call pair is the sampled one (counted across steps)
+        for g in range(0, B, fpc):
+            n = min(fpc, B - g)
+            calls[0] += 1
+            sampled = profile and calls[0] % args.profile_every == 1
+            if sampled:
+                ctxs[0].profile_arm(2)
+            encs[0].EncodeFramesGPU(sat_ptr[:n], frame_ptr[g:g + n], w, h, 4 * w)
+            decs[0].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n], (w, h),
+                                        gazes[g:g + n])
+
     def step(profile):
+        if fpc > 1:
+            return step_batched(profile)
         for k in range(B):
             s = k % nstreams
             sampled = profile and k % args.profile_every == 0
@@ -316,7 +342,16 @@ def main():
             a = prof.setdefault(name, [0.0, 0])
             a[0] += ms
             a[1] += n
+    frames_of = {}
+    for c in ctxs:
+        for name, n in c.profile_frames().items():
+            frames_of[name] = frames_of.get(name, 0) + n
     kernels = {name: {"avg_us": round(1e3 * ms / n, 2), "launches": n} for name, (ms, n) in prof.items()}
+    for name, k in kernels.items():  # a batched call's launch covers several frames
+        fpl = frames_of.get(name, k["launches"]) / k["launches"]
+        if fpl != 1:
+            k["frames_per_launch"] = round(fpl, 2)
+            k["avg_us_per_frame"] = round(k["avg_us"] / fpl, 2)
 
     value = total_px / 1e6 / elapsed
     enc_bytes, smp_bytes = algorithmic_bytes(w, h, rw, rh)
@@ -335,6 +370,8 @@ def main():
         if dom in kernels:
             avg_s = kernels[dom]["avg_us"] * 1e-6
             dom_bytes = frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes
+            fpl = kernels[dom].get("frames_per_launch", 1)  # frames one launch of it covers
+            dom_bytes = int(dom_bytes * fpl)
             achieved = dom_bytes / avg_s / 1e9
             # PMC traffic is a measurement of a particular build: profiles/pmc_traffic.json carries
             # the hash of the kernel sources it was taken on and is ignored (null) for any other
@@ -348,6 +385,8 @@ def main():
                         doc = json.load(f)
                     if doc.get("csrc_sha") == csrc_hash():
                         traffic = doc.get(dom, {}).get(f"{w}x{h}" + (":yuv420p" if yuv else ""))
+                        if traffic is not None:
+                            traffic = int(traffic * fpl)
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom + (" (emit mode)" if args.fused else ""),
@@ -377,11 +416,13 @@ def main():
                                    + (f"ONE batch of {args.global_batch} frames per step sharded over "
                                       f"the GPUs in contiguous blocks" if args.global_batch else
                                       f"batch {B} frames per GPU per step")
+                                   + (f" ({fpc} frames per encode call and per sample call)"
+                                      if fpc > 1 else "")
                                    + ", Lissajous gaze, inputs resident in HBM",
                        "source": args.source, "fused": bool(args.fused),
                        "frame": [w, h], "reduced": [rw, rh], "batch_per_gpu": B,
                        "global_batch": args.global_batch or None,
-                       "streams_per_gpu": nstreams, "parallelism": f"frames sharded x{world}"},
+                       "streams_per_gpu": nstreams, "frames_per_call": fpc, "parallelism": f"frames sharded x{world}"},
             "roofline": roof,
             "path_hbm_frac": round(path_bytes * (total_px / (w * h)) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "kernels": kernels,

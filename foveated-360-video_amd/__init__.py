@@ -87,6 +87,9 @@ _SIGNATURES = {
     "f360_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "f360_sat_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "f360_sat_encode_prepare": (c_int, [c_void_p, c_int, c_int]),
+    "f360_sat_encode_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
+                                      c_int, c_int]),
+    "f360_sat_encode_batch_max": (c_int, []),
     "f360_yuv420p_to_rgb0": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int]),
     "f360_rgb0_to_yuv420p": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -101,6 +104,9 @@ _SIGNATURES = {
                                         c_int, c_int, c_float, c_float]),
     "f360_satdec_sample_rect_batch": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                               c_int, c_void_p, c_int, c_int, POINTER(c_float)]),
+    "f360_satdec_sample_rect_frames": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
+                                               c_int, POINTER(c_void_p), c_int, c_int,
+                                               POINTER(c_float)]),
     "f360_satdec_foveate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                          c_int, c_int, c_float, c_float]),
     "f360_satdec_foveate_rect_yuv420p": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
@@ -133,6 +139,7 @@ _SIGNATURES = {
     "f360_kernel_name": (c_char_p, [c_int]),
     "f360_ctx_profile_arm": (c_int, [c_void_p, c_int]),
     "f360_ctx_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
+    "f360_ctx_profile_frames": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "f360_ctx_profile_reset": (c_int, [c_void_p]),
     "f360_tables_satdec_grid_axis": (c_int, [c_void_p, c_int, c_int]),
     "f360_tables_is_grid_axis": (c_int, [c_void_p, c_int, c_int]),
@@ -253,6 +260,17 @@ class Context:
                 out[lib().f360_kernel_name(k).decode()] = (ms.value, n.value)
         return out
 
+    def profile_frames(self) -> dict:
+        """{kernel name: frames} the sampled launches covered (a batched call's launch covers
+        several frames)."""
+        out = {}
+        for k in range(lib().f360_kernel_count()):
+            n = c_int(0)
+            _check(lib().f360_ctx_profile_frames(self._h, k, byref(n)))
+            if n.value:
+                out[lib().f360_kernel_name(k).decode()] = n.value
+        return out
+
     def malloc(self, nbytes: int) -> "DeviceBuffer":
         return DeviceBuffer(self, nbytes)
 
@@ -352,6 +370,22 @@ class SATEncoder:
                                      _p(cl_source_buffer), source_width, source_height,
                                      source_linesize))
 
+    def EncodeFramesGPU(self, cl_target_buffers, cl_source_buffers, source_width: int,
+                        source_height: int, source_linesize: int) -> None:
+        """EncodeFrameGPU for several frames of one geometry in shared launches
+        (f360_sat_encode_batch): lists of device pointers, table k of source k.  Not in the
+        reference."""
+        if self.cl_manager is None:
+            raise F360Error(F360_ERR_NOT_INITIALIZED,
+                            "[SATEncoder::EncodeFramesGPU] Not initialized with OpenCL")
+        n = len(cl_target_buffers)
+        if n != len(cl_source_buffers):
+            raise ValueError("EncodeFramesGPU: as many tables as sources")
+        sats = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        srcs = (c_void_p * n)(*[int(p) for p in cl_source_buffers])
+        _check(lib().f360_sat_encode_batch(self.cl_manager.handle, n, sats, srcs, source_width,
+                                           source_height, source_linesize))
+
     def EncodeFrameYUV420PGPU(self, cl_target_buffer, cl_y, cl_u, cl_v, y_linesize: int,
                               u_linesize: int, v_linesize: int, source_width: int,
                               source_height: int) -> None:
@@ -416,6 +450,23 @@ class SATDecoder:
         _check(lib().f360_satdec_sample_rect_batch(self._h, ptrs, n, target_width,
                                                    target_height, target_linesize,
                                                    _p(cl_source_buffer), w, h, xy))
+
+    def SampleFramesRectGPU(self, cl_target_buffers, target_width, target_height,
+                            target_linesize, cl_source_buffers, codec_ctx, centers) -> None:
+        """Frame k's table sampled at gaze k into target k, shared launches
+        (f360_satdec_sample_rect_frames); lists of device pointers and of (cx, cy)."""
+        self._need("SampleFramesRectGPU")
+        w, h = (codec_ctx if isinstance(codec_ctx, tuple)
+                else (codec_ctx.width, codec_ctx.height))
+        n = len(cl_target_buffers)
+        if n != len(cl_source_buffers) or n != len(centers):
+            raise ValueError("SampleFramesRectGPU: as many targets as tables and gaze points")
+        ptrs = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        sats = (c_void_p * n)(*[int(p) for p in cl_source_buffers])
+        xy = (c_float * (2 * n))(*[float(v) for c in centers for v in c])
+        _check(lib().f360_satdec_sample_rect_frames(self._h, ptrs, n, target_width,
+                                                    target_height, target_linesize, sats, w, h,
+                                                    xy))
 
     def FoveateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
                             target_linesize, cl_source_frame, source_width, source_height,

@@ -77,7 +77,9 @@ struct SatEncodePlan {
   int sb_bands = 0;    // bands per super-band (tile height of the reducer)
   int nstrips = 0, nbands = 0, nsb = 0;
   int wp3 = 0;         // 3 * padded width (padded to whole 256-pixel strips)
-  DevBuf ws;           // one allocation, carved below
+  DevBuf ws;           // one allocation, carved below (`frames` slices of ws_stride elements)
+  int frames = 0;      // frames the scratch can hold at once (f360_sat_encode_batch)
+  size_t ws_stride = 0;
   uint32_t *lp = nullptr;        // [nbands][wp3]  column sums above the band, inside its super-band
   uint32_t *sbtotal = nullptr;   // [nsb][wp3]     column sums of each super-band
   uint32_t *sbprefix = nullptr;  // [nsb][wp3]     column sums of all super-bands above
@@ -113,6 +115,7 @@ enum KernelId {
 struct ProfSpan {
   int kid;
   hipEvent_t a, b;
+  int frames;  // frames the launch covered (batched calls)
 };
 }  // namespace f360
 
@@ -152,6 +155,7 @@ struct f360_ctx {
   std::vector<hipEvent_t> prof_free;
   double prof_ms[f360::kKernelCount] = {};
   int prof_launches[f360::kKernelCount] = {};
+  int prof_frames[f360::kKernelCount] = {};
 };
 
 namespace f360 {
@@ -159,7 +163,8 @@ namespace f360 {
 // current call is being sampled.
 class KernelSpan {
  public:
-  KernelSpan(f360_ctx *ctx, int kid, bool on) : ctx_(ctx), kid_(kid), on_(on) {
+  KernelSpan(f360_ctx *ctx, int kid, bool on, int frames = 1)
+      : ctx_(ctx), kid_(kid), on_(on), frames_(frames) {
     if (!on_) return;
     a_ = take();
     b_ = take();
@@ -169,7 +174,7 @@ class KernelSpan {
   ~KernelSpan() {
     if (!on_) return;
     (void)hipEventRecord(b_, ctx_->stream);
-    ctx_->prof_pending.push_back(ProfSpan{kid_, a_, b_});
+    ctx_->prof_pending.push_back(ProfSpan{kid_, a_, b_, frames_});
   }
  private:
   hipEvent_t take() {
@@ -185,6 +190,7 @@ class KernelSpan {
   f360_ctx *ctx_;
   int kid_;
   bool on_;
+  int frames_;
   hipEvent_t a_ = nullptr, b_ = nullptr;
 };
 // true when this call is sampled; consumes one armed call
@@ -205,8 +211,13 @@ struct SatEmit {
   const FovMaps *maps;  // non-null: the reducer's launch also computes the lattice maps
 };
 // `yuv` non-null: the pixels come from three planes (src_dev / linesize unused)
+// `count` > 0: a batch of frames of one geometry (tables sats[k] of sources srcs[k]; sat_dev /
+// src_dev unused, no emit, no planes).  `profile`: -1 = take a profile slot if one is armed,
+// 0 / 1 = the caller already decided (one slot per batched call, however many launches)
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
-                    int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv);
+                    int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
+                    int count = 0, uint32_t *const *sats = nullptr,
+                    const uint8_t *const *srcs = nullptr, int profile = -1);
 }  // namespace f360
 
 struct f360_event {

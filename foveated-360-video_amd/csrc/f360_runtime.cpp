@@ -337,6 +337,7 @@ static int profile_collect(f360_ctx *ctx) {
     F360_HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
     ctx->prof_ms[s.kid] += (double)ms;
     ctx->prof_launches[s.kid] += 1;
+    ctx->prof_frames[s.kid] += s.frames;
     ctx->prof_free.push_back(s.a);
     ctx->prof_free.push_back(s.b);
   }
@@ -357,6 +358,16 @@ int f360_ctx_profile_read(f360_ctx *ctx, int kernel_id, double *total_ms,
   return F360_OK;
 }
 
+int f360_ctx_profile_frames(f360_ctx *ctx, int kernel_id, int *frames) {
+  F360_REQUIRE(ctx && frames && kernel_id >= 0 && kernel_id < f360::kKernelCount,
+               "f360_ctx_profile_frames: bad argument");
+  F360_BIND_DEVICE(ctx);
+  int st = profile_collect(ctx);
+  if (st != F360_OK) return st;
+  *frames = ctx->prof_frames[kernel_id];
+  return F360_OK;
+}
+
 int f360_ctx_profile_reset(f360_ctx *ctx) {
   F360_REQUIRE(ctx, "f360_ctx_profile_reset: null context");
   F360_BIND_DEVICE(ctx);
@@ -365,6 +376,7 @@ int f360_ctx_profile_reset(f360_ctx *ctx) {
   for (int k = 0; k < f360::kKernelCount; ++k) {
     ctx->prof_ms[k] = 0.0;
     ctx->prof_launches[k] = 0;
+    ctx->prof_frames[k] = 0;
   }
   return F360_OK;
 }

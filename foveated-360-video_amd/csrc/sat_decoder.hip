@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void sample_rect_walk_kernel(const SampleArgs 
 constexpr int kMaxBatch = 16;
 struct SampleBatch {
   uint8_t *dst[kMaxBatch];
+  const uint32_t *sat[kMaxBatch];  // the same table for every client, or one per frame
   int cxp[kMaxBatch], cyp[kMaxBatch];
 };
 
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256) void sample_rect_walk_batch_kernel(SampleArgs 
   if (c0 >= a.out_w) return;  // whole wave
   const int z = blockIdx.z;
   a.dst = b.dst[z];
+  a.sat = b.sat[z];
   a.cxp = b.cxp[z];
   a.cyp = b.cyp[z];
   const int j0 = (int)blockIdx.y * rows;
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(256) void sample_rect_stream_batch_kernel(SampleArg
   const int wave = threadIdx.x >> 6;
   const int z = blockIdx.y;
   a.dst = b.dst[z];
+  a.sat = b.sat[z];
   a.cxp = b.cxp[z];
   a.cyp = b.cyp[z];
   const int ntiles = (a.src_w + kTsTile - 1) / kTsTile;
@@ -963,14 +966,15 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   return F360_OK;
 }
 
-int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets_dev,
-                                  int count, int target_width, int target_height,
-                                  int target_linesize, const uint32_t *sat_dev,
+// `sats_dev` null: every gaze samples `sat_dev` (clients of one video); else frame k's table
+static int sample_rect_batch_impl(f360_sat_decoder *dec, uint8_t *const *targets_dev, int count,
+                                  int target_width, int target_height, int target_linesize,
+                                  const uint32_t *sat_dev, const uint32_t *const *sats_dev,
                                   int source_width, int source_height,
-                                  const float *centers_xy) {
+                                  const float *centers_xy, int profile = -1) {
   F360_REQUIRE(dec, "f360_satdec_sample_rect_batch: null decoder");
   F360_BIND_DEVICE(dec->ctx);
-  F360_REQUIRE(targets_dev && sat_dev && centers_xy,
+  F360_REQUIRE(targets_dev && (sat_dev || sats_dev) && centers_xy,
                "f360_satdec_sample_rect_batch: null buffer");
   F360_REQUIRE(count >= 1 && count <= kMaxBatch,
                "f360_satdec_sample_rect_batch: count %d outside 1..%d", count, kMaxBatch);
@@ -994,6 +998,8 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
     F360_REQUIRE(std::fabs(centers_xy[2 * q]) <= 16.0f && std::fabs(centers_xy[2 * q + 1]) <= 16.0f,
                  "f360_satdec_sample_rect_batch: gaze centre out of range");
     b.dst[k] = targets_dev[q];
+    b.sat[k] = sats_dev ? sats_dev[q] : sat_dev;
+    F360_REQUIRE(b.sat[k], "f360_satdec_sample_rect_batch: null table %d", q);
     b.cxp[k] = (int)(centers_xy[2 * q] * (float)source_width);
     b.cyp[k] = (int)(centers_xy[2 * q + 1] * (float)source_height);
   }
@@ -1001,7 +1007,7 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
   sa.out_w = target_width;
   sa.out_h = target_height;
   sa.out_stride_px = target_linesize / 4;
-  sa.sat = sat_dev;
+  sa.sat = b.sat[0];
   sa.src_w = source_width;
   sa.src_h = source_height;
   sa.gx = dec->gx_dev.as<int16_t>();
@@ -1012,13 +1018,14 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
   sa.halo = dec->halo;
   f360_ctx *ctx = dec->ctx;
   sa.ablate = ctx->opt_ablate;
-  f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
+  f360::KernelSpan span(ctx, f360::kSampleRect,
+                        profile < 0 ? f360::take_profile_slot(ctx) : profile != 0, count);
   // the tile streamer when every client's gaze passes its host checks, else the walker for all
-  bool stream = ctx->opt_sample_variant == 2 &&
-                tile_stream_applies(dec, sat_dev, source_width, source_height, target_linesize,
-                                    target_height);
+  bool stream = ctx->opt_sample_variant == 2;
   for (int k = 0; k < count && stream; ++k)
-    stream = tile_stream_fits(dec, b.cxp[k], source_width, target_width);
+    stream = tile_stream_applies(dec, b.sat[k], source_width, source_height, target_linesize,
+                                 target_height) &&
+             tile_stream_fits(dec, b.cxp[k], source_width, target_width);
   if (stream) {
     const int ntiles = (source_width + kTsTile - 1) / kTsTile;
     const int rows = std::min(ctx->opt_stream_rows, kTsMaxRows);
@@ -1041,6 +1048,36 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
                        rows);
   }
   F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+
+int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                  int count, int target_width, int target_height,
+                                  int target_linesize, const uint32_t *sat_dev,
+                                  int source_width, int source_height,
+                                  const float *centers_xy) {
+  F360_REQUIRE(sat_dev, "f360_satdec_sample_rect_batch: null table");
+  return sample_rect_batch_impl(dec, targets_dev, count, target_width, target_height,
+                                target_linesize, sat_dev, nullptr, source_width, source_height,
+                                centers_xy);
+}
+
+int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                   int count, int target_width, int target_height,
+                                   int target_linesize, const uint32_t *const *sats_dev,
+                                   int source_width, int source_height,
+                                   const float *centers_xy) {
+  F360_REQUIRE(dec && sats_dev && count >= 1, "f360_satdec_sample_rect_frames: bad arguments");
+  const int prof = f360::take_profile_slot(dec->ctx) ? 1 : 0;  // one slot for the whole call
+  // more frames than one launch holds: consecutive launches
+  for (int k = 0; k < count; k += kMaxBatch) {
+    const int n = std::min(count - k, kMaxBatch);
+    const int st = sample_rect_batch_impl(dec, targets_dev + k, n, target_width, target_height,
+                                          target_linesize, nullptr, sats_dev + k, source_width,
+                                          source_height, centers_xy + 2 * k, prof);
+    if (st != F360_OK) return st;
+  }
   return F360_OK;
 }
 

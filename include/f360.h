@@ -138,6 +138,20 @@ int f360_rgb0_to_yuv420p(f360_ctx *ctx, uint8_t *y_dev, uint8_t *u_dev, uint8_t 
 int f360_sat_encode_yuv420p(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *y_dev,
                             const uint8_t *u_dev, const uint8_t *v_dev, int y_linesize,
                             int u_linesize, int v_linesize, int width, int height);
+/* SATEncoder::EncodeFrameGPU for `count` frames of one geometry at once: table sat_dev[k] of
+ * source src_dev[k] (HOST arrays of device pointers), the same bytes as `count` single calls.
+ * The frames share each of the encoder's three launches (a grid dimension of their own), which
+ * is what small frames need: a 1080p frame alone cannot fill the device and its three launches
+ * cost more than its traffic (16 per launch: 2.5 times the throughput).  The call splits into
+ * launches of as many frames as stay cache-resident between the encoder's two reads of them
+ * (about 144 MB of source, at most f360_sat_encode_batch_max() = 16: one 8K frame, four
+ * 3840x1920 frames, sixteen 1080p frames).  Not in the
+ * reference, whose encoder handles one frame per call (src/sat_encoder.cc:67-135); a server
+ * that holds several decoded frames, or several connections on one GPU, can use it.  The
+ * encoder's scratch grows to `count` frames' worth (17 MB per 8K frame). */
+int f360_sat_encode_batch(f360_ctx *ctx, int count, uint32_t *const *sat_dev,
+                          const uint8_t *const *src_dev, int width, int height, int linesize);
+int f360_sat_encode_batch_max(void);
 
 /* ---- SATDecoder --------------------------------------------------------- */
 int f360_satdec_create(f360_ctx *ctx, f360_sat_decoder **out);
@@ -172,6 +186,14 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec,
                                   int target_linesize, const uint32_t *sat_dev,
                                   int source_width, int source_height,
                                   const float *centers_xy);
+/* The same launch shape for several FRAMES: target k is frame k's table sats_dev[k] sampled at
+ * gaze k (any count; launches of 16).  The counterpart of f360_sat_encode_batch.  All three
+ * arrays are HOST arrays. */
+int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                   int count, int target_width, int target_height,
+                                   int target_linesize, const uint32_t *const *sats_dev,
+                                   int source_width, int source_height,
+                                   const float *centers_xy);
 /* Fused SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for a gaze that
  * is known before the encode (the reference's offline modes read it from a trace,
  * src/run_satlogrectilinear.cc:926-938): frame -> reduced frame, the same bytes as
@@ -329,6 +351,8 @@ const char *f360_kernel_name(int kernel_id);
 int f360_ctx_profile_arm(f360_ctx *ctx, int calls);
 int f360_ctx_profile_read(f360_ctx *ctx, int kernel_id, double *total_ms,
                           int *launches);
+/* frames those launches covered (a batched call's launch covers several) */
+int f360_ctx_profile_frames(f360_ctx *ctx, int kernel_id, int *frames);
 int f360_ctx_profile_reset(f360_ctx *ctx);
 
 #ifdef __cplusplus

@@ -80,6 +80,27 @@ class SATDecoder {
                 << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 
+  // Not in the reference: `count` frames in shared launches -- target k is table k sampled at
+  // (centers_xy[2k], centers_xy[2k+1]); the counterpart of SATEncoder::EncodeFramesGPU.
+  template <class CodecContext>
+  void SampleFramesRectGPU(int count, cl_mem const *cl_target_buffers, int target_width,
+                           int target_height, int target_linesize,
+                           cl_mem const *cl_source_buffers, CodecContext *codec_ctx,
+                           const float *centers_xy) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::SampleFramesRectGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_sample_rect_frames(
+        impl, reinterpret_cast<uint8_t *const *>(cl_target_buffers), count, target_width,
+        target_height, target_linesize,
+        reinterpret_cast<const uint32_t *const *>(cl_source_buffers), codec_ctx->width,
+        codec_ctx->height, centers_xy);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::SampleFramesRectGPU] Sample rect kernel launch failed:" << ret
+                << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
   // Not in the reference: EncodeFrameGPU + SampleFrameRectGPU fused for a gaze known before the
   // encode (its offline modes, src/run_satlogrectilinear.cc:926-938); same bytes, no table.
   void FoveateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,

@@ -37,6 +37,23 @@ class SATEncoder {
                 << f360_last_error_string() << std::endl;
   }
 
+  // Not in the reference: `count` frames of one geometry in shared launches (table k of source
+  // k), what small frames and many connections per GPU want (f360_sat_encode_batch).
+  void EncodeFramesGPU(int count, cl_mem const *cl_target_buffers, cl_mem const *cl_source_buffers,
+                       int source_width, int source_height, int source_linesize) {
+    if (!use_OpenCL) {
+      std::cerr << "[SATEncoder::EncodeFramesGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_sat_encode_batch(
+        cl_manager->context.get(), count, reinterpret_cast<uint32_t *const *>(cl_target_buffers),
+        reinterpret_cast<const uint8_t *const *>(cl_source_buffers), source_width, source_height,
+        source_linesize);
+    if (ret != F360_OK)
+      std::cerr << "[SATEncoder::EncodeFramesGPU] kernel launch failed:" << ret << " "
+                << f360_last_error_string() << std::endl;
+  }
+
   // src/sat_encoder.cc:137-185: the same table on the host (uint32 [height][width][3]).
   template <class CodecContext, class Frame>
   void EncodeFrameCPU(uint32_t *target_frame, CodecContext *codec_ctx, Frame *frame) {

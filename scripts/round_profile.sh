@@ -7,12 +7,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 python $R/bench.py > $O/${tag}_bench_default.json || exit 1
+python $R/bench.py --frames-per-call 1 --no-cpu-baseline > $O/${tag}_bench_per_frame_calls.json || exit 1
 python $R/bench.py --streams 3 --no-cpu-baseline > $O/${tag}_bench_streams3.json || exit 1
 python $R/bench.py --source yuv420p --no-cpu-baseline > $O/${tag}_bench_yuv420p.json || exit 1
 python $R/bench.py --fused --no-cpu-baseline > $O/${tag}_bench_fused.json || exit 1
 python $R/bench.py --fused --source yuv420p --no-cpu-baseline > $O/${tag}_bench_fused_yuv420p.json || exit 1
 python $R/bench.py --fused --source yuv420p --streams 3 --no-cpu-baseline > $O/${tag}_bench_fused_yuv420p_streams3.json || exit 1
 python $R/bench_kernels.py > $O/${tag}_bench_kernels_8k.json || exit 1
+python $R/tests/bench_configs.py --config all > $O/${tag}_bench_configs.jsonl 2> $O/${tag}_bench_configs.err || exit 1
 echo "bench lines done"
 # the default command itself under the kernel tracer: its JSON line and the tracer's per-kernel
 # averages come from the same run

@@ -65,6 +65,23 @@ def config2(f360, ob, quick):
         run()
         ctx.finish()
         dt = time.perf_counter() - t0
+
+        # the same frames, 16 per EncodeFramesGPU / SampleFramesRectGPU call
+        def run_batched():
+            for g in range(0, n, 16):
+                m = min(16, n - g)
+                enc.EncodeFramesGPU([s.ptr for s in sat[g:g + m]], [s.ptr for s in src[g:g + m]],
+                                    w, h, 4 * w)
+                dec.SampleFramesRectGPU([r.ptr for r in red[g:g + m]], rw, rh, 4 * rw,
+                                        [s.ptr for s in sat[g:g + m]], (w, h), gaze[g:g + m])
+        for b in sat + red:
+            b.fill(0)
+        run_batched()
+        ctx.finish()
+        t0 = time.perf_counter()
+        run_batched()
+        ctx.finish()
+        dt_b = time.perf_counter() - t0
         grid = ob.satdec_grid(rw, rh, w, h)
         bad = 0
         for k in range(n):
@@ -80,7 +97,11 @@ def config2(f360, ob, quick):
     return {"config": 2, "workload": f"{n} frames {w}x{h} SAT encode + sample_rect to {rw}x{rh}",
             "mpix_per_s": round(n * w * h / 1e6 / dt, 1), "us_per_frame": round(1e6 * dt / n, 2),
             "hbm_frac_algorithmic": round((enc_b + smp_b) * n / dt / 8e12, 4),
-            "parity": f"{n - bad}/{n} frames SAT and reduced frame bit-exact vs oracle"}
+            "mpix_per_s_16_frames_per_call": round(n * w * h / 1e6 / dt_b, 1),
+            "us_per_frame_16_frames_per_call": round(1e6 * dt_b / n, 2),
+            "hbm_frac_algorithmic_16_frames_per_call": round((enc_b + smp_b) * n / dt_b / 8e12, 4),
+            "parity": f"{n - bad}/{n} frames SAT and reduced frame bit-exact vs oracle "
+                      f"(the buffers compared are those the batched calls wrote last)"}
 
 
 def config4_frames(ob, indices, w, h):

@@ -1230,3 +1230,102 @@ def test_config4_shard_digests_8k(f360, oracle):
     assert list(shard) == list(range(56, 64))
     res = bench_configs.config4(f360, oracle, quick=True, indices=list(shard) + [64])
     assert res["bad_frames"] == [], res
+
+
+# --------------------------------------------------------------- frames in shared launches
+@pytest.mark.parametrize("w,h,bpp,pad,n", [
+    (1336, 203, 4, 0, 5),     # vector path, ragged tiles
+    (1920, 1080, 4, 0, 3),
+    (999, 37, 4, 0, 4),       # width % 4 != 0 -> scalar path for the whole batch
+    (640, 48, 3, 0, 2),       # RGB24
+    (256, 128, 4, 16, 19),    # more frames than one launch holds (16): split
+])
+def test_sat_encode_batch_matches_oracle(f360, gpu_ctx, oracle, w, h, bpp, pad, n):
+    """f360_sat_encode_batch: every frame's table is the oracle's, whatever came before in the
+    context (a single encode, a batch of another size: the scratch is re-carved)."""
+    ls = w * bpp + pad
+    frames = [oracle.lcg_frame(w, h, 900 + k, bpp=bpp, linesize=ls) for k in range(n)]
+    srcs = [gpu_ctx.upload(np.ascontiguousarray(f).reshape(-1)) for f in frames]
+    sats = [gpu_ctx.malloc(w * h * 12) for _ in range(n)]
+    for s in sats:
+        s.fill(0xEE)
+    enc = f360.SATEncoder(gpu_ctx)
+    enc.EncodeFrameGPU(sats[0].ptr, srcs[0].ptr, w, h, ls)          # single, then the batch
+    enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, ls)
+    for k in range(n):
+        want = oracle.sat_encode(frames[k], w, h, ls)
+        assert np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want), k
+    # a smaller batch and a single call afterwards still work on the larger scratch
+    for s in sats[:2]:
+        s.fill(0x11)
+    enc.EncodeFramesGPU([sats[1].ptr, sats[0].ptr], [srcs[0].ptr, srcs[1].ptr], w, h, ls)
+    assert np.array_equal(sats[1].copy_to_host(np.uint32, (h, w, 3)),
+                          oracle.sat_encode(frames[0], w, h, ls))
+    assert np.array_equal(sats[0].copy_to_host(np.uint32, (h, w, 3)),
+                          oracle.sat_encode(frames[1], w, h, ls))
+    enc.EncodeFrameGPU(sats[0].ptr, srcs[n - 1].ptr, w, h, ls)
+    assert np.array_equal(sats[0].copy_to_host(np.uint32, (h, w, 3)),
+                          oracle.sat_encode(frames[n - 1], w, h, ls))
+    with pytest.raises(f360.F360Error):
+        enc.EncodeFramesGPU([sats[0].ptr, 0], [srcs[0].ptr, srcs[1].ptr], w, h, ls)
+    for b in srcs + sats:
+        b.free()
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_encode_and_sample_frames_match_oracle(f360, gpu_ctx, oracle, variant):
+    """The batched two-call path: n frames encoded in shared launches, then frame k's table
+    sampled at gaze k in shared launches -- every reduced frame is the oracle's (tile streamer
+    and walker; 18 frames: two launches of the sampler)."""
+    gpu_ctx.set_option("sample.variant", variant)
+    w, h, n = 1024, 512, 18
+    rw, rh = reduced(w), reduced(h)
+    frames = [oracle.lcg_frame(w, h, 40 + k) for k in range(n)]
+    gazes = [(GAZES + EXTRA_GAZES)[k % 9] for k in range(n)]
+    srcs = [gpu_ctx.upload(f) for f in frames]
+    sats = [gpu_ctx.malloc(w * h * 12) for _ in range(n)]
+    reds = [gpu_ctx.malloc(rw * rh * 4) for _ in range(n)]
+    for r in reds:
+        r.fill(0xA5)
+    enc, dec = f360.SATEncoder(gpu_ctx), f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, 4 * w)
+    dec.SampleFramesRectGPU([r.ptr for r in reds], rw, rh, 4 * rw, [s.ptr for s in sats], (w, h),
+                            gazes)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    for k in range(n):
+        sat_h = oracle.sat_encode(frames[k], w, h, 4 * w)
+        want = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, 4 * rw, sat_h, w, h, grid, *gazes[k])
+        assert np.array_equal(reds[k].copy_to_host(np.uint8, (rh, 4 * rw)), want), (k, gazes[k])
+    gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
+    for b in srcs + sats + reds:
+        b.free()
+    dec.close()
+
+
+def test_batched_path_8k_digests(f360, gpu_ctx, oracle, golden_digests):
+    """Full size: three 8K frames through the batched encode and sample; the golden frame among
+    them gives the golden table and reduced-frame digests."""
+    w, h = 7680, 3840
+    rw, rh = reduced(w), reduced(h)
+    ent = golden_digests["cases"][f"{w}x{h}"]
+    gaze = golden_digests["gazes"][2]
+    frames = [oracle.lcg_frame(w, h, 7), oracle.lcg_frame(w, h, golden_digests["seed"]),
+              np.full((h, 4 * w), 255, dtype=np.uint8)]
+    srcs = [gpu_ctx.upload(f) for f in frames]
+    sats = [gpu_ctx.malloc(w * h * 12) for _ in frames]
+    reds = [gpu_ctx.malloc(rw * rh * 4) for _ in frames]
+    for r in reds:
+        r.fill(0xA5)
+    enc, dec = f360.SATEncoder(gpu_ctx), f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, 4 * w)
+    dec.SampleFramesRectGPU([r.ptr for r in reds], rw, rh, 4 * rw, [s.ptr for s in sats], (w, h),
+                            [gaze] * 3)
+    assert f"{oracle.fnv1a64(sats[1].copy_to_host(np.uint32, (h, w, 3))):016x}" == ent["sat"]
+    assert f"{oracle.fnv1a64(sats[2].copy_to_host(np.uint32, (h, w, 3))):016x}" == ent["sat_white"]
+    assert f"{oracle.fnv1a64(reds[1].copy_to_host(np.uint8, (rh, 4 * rw))):016x}" == ent["sample_rect_2"]
+    for b in srcs + sats + reds:
+        b.free()
+    dec.close()
