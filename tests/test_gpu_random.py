@@ -215,3 +215,43 @@ def test_random_planar_sources(f360, gpu_ctx, oracle):
     finally:
         for k, v_ in old.items():
             gpu_ctx.set_option(k, v_)
+
+
+def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
+    """EncodeFramesGPU + SampleFramesRectGPU on random geometries, batch sizes (1 .. 20: more
+    than a launch holds), pixel formats and gaze points; every frame against the oracle."""
+    rng = np.random.default_rng(4242)
+    enc = f360.SATEncoder(gpu_ctx)
+    for case in range(24):
+        w, h = random_geometry(rng)
+        w, h = max(w, 4), max(h, 4)
+        if case % 3 == 0:
+            w = (w + 3) // 4 * 4 + 4      # the vector / tile-streamer path
+        n = int(rng.integers(1, 21))
+        bpp = 4 if case % 4 else 3
+        ls = w * bpp
+        rw, rh = reduced(w), reduced(h)
+        gpu_ctx.set_option("sample.variant", int(rng.choice([1, 2, 2])))
+        frames = [rng.integers(0, 256, (h, ls), dtype=np.uint8) for _ in range(n)]
+        gazes = [random_gaze(rng) for _ in range(n)]
+        srcs = [gpu_ctx.upload(f) for f in frames]
+        sats = [gpu_ctx.malloc(w * h * 12) for _ in range(n)]
+        reds = [gpu_ctx.malloc(rw * rh * 4) for _ in range(n)]
+        for r in reds:
+            r.fill(0x5A)
+        dec = f360.SATDecoder(gpu_ctx)
+        dec.InitializeGrid(rw, rh, w, h)
+        enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, ls)
+        dec.SampleFramesRectGPU([r.ptr for r in reds], rw, rh, 4 * rw, [s.ptr for s in sats],
+                                (w, h), gazes)
+        grid = oracle.satdec_grid(rw, rh, w, h)
+        for k in range(n):
+            sat_h = oracle.sat_encode(frames[k], w, h, ls)
+            assert np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), sat_h), (case, k, w, h)
+            want = np.full((rh, 4 * rw), 0x5A, dtype=np.uint8)
+            oracle.satdec_sample_rect(want, rw, rh, 4 * rw, sat_h, w, h, grid, *gazes[k])
+            assert np.array_equal(reds[k].copy_to_host(np.uint8, (rh, 4 * rw)), want), (case, k, w, h, gazes[k])
+        for b in srcs + sats + reds:
+            b.free()
+        dec.close()
+    gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
