@@ -823,7 +823,11 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
   // offset is >= d; plus the largest step between neighbouring corners (its halo)
   {
     const std::vector<int16_t> &g = dec->gx_host;
-    const int dmin = g.front(), dmax = g.back() + 1;
+    // A degenerate geometry (a reduced width of 2 or 3 for a wider source) overflows the
+    // reference's float -> int conversion and leaves a grid that is not even monotonic
+    // (e.g. {11668, -2, 1}); the gather kernels take any grid, the streamer needs the inverse.
+    const bool monotonic = std::is_sorted(g.begin(), g.end());
+    const int dmin = monotonic ? (int)g.front() : 0, dmax = monotonic ? (int)g.back() + 1 : 0;
     std::vector<int> lb((size_t)(dmax - dmin + 1));
     size_t gi = 0;
     for (int d = dmin; d <= dmax; ++d) {
@@ -838,7 +842,8 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
     dec->lb_dmin = dmin;
     dec->lb_n = (int)lb.size();
     // a tile's halo is at most 512 bytes (42 texels); box heights travel in 8 bits
-    dec->stream_ok = dec->halo <= 40 && max_step_y < 256;
+    dec->stream_ok = monotonic && dec->halo <= 40 && max_step_y < 256 &&
+                     std::is_sorted(dec->gy_host.begin(), dec->gy_host.end());
     st = upload(dec->ctx, dec->lbx_dev, lb.data(), lb.size() * sizeof(int));
     if (st != F360_OK) return st;
     dec->lbx_host = std::move(lb);

@@ -1329,3 +1329,27 @@ def test_batched_path_8k_digests(f360, gpu_ctx, oracle, golden_digests):
     for b in srcs + sats + reds:
         b.free()
     dec.close()
+
+
+def test_degenerate_reduced_width_grid(f360, gpu_ctx, oracle):
+    """A reduced width of 2 for a wider source overflows the reference's float -> int conversion:
+    the x grid is {11668, -2, 1}, not even monotonic.  The grid, the sampler (every variant) and
+    the fused call still reproduce the restatement (found by the fuzz soak: the tile streamer's
+    inverse-grid table used to be sized by last - first)."""
+    w, h, rw, rh = 4, 13, 2, 21
+    frame = oracle.lcg_frame(w, h, 9)
+    sat_h = oracle.sat_encode(frame, w, h, 4 * w)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    assert not np.all(np.diff(grid[0, :, 0].astype(int)) >= 0)
+    dec = f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    assert np.array_equal(dec.export_grid(rw, rh), grid)
+    for variant in SAMPLER_VARIANTS:
+        gpu_ctx.set_option("sample.variant", variant)
+        for (cx, cy) in GAZES[:3]:
+            want = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+            oracle.satdec_sample_rect(want, rw, rh, 4 * rw, sat_h, w, h, grid, cx, cy)
+            got = run_sample_rect(f360, gpu_ctx, dec, sat_h, w, h, rw, rh, cx, cy)
+            assert np.array_equal(got, want), (variant, cx, cy)
+    gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
+    dec.close()

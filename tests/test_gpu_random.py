@@ -2,6 +2,7 @@
 frame sizes (down to 2x2), pixel formats, row paddings, reduced sizes, gaze points (inside and
 outside [0,1]) and engine options.  Catches the edge cases fixed-size tests miss."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -11,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 SAMPLER_VARIANTS = (0, 1, 2)
 DEFAULT_SAMPLER = 2
+# F360_FUZZ_SCALE=10 runs ten times as many cases (a longer soak outside the regular tier)
+SCALE = max(1, int(os.environ.get("F360_FUZZ_SCALE", "1")))
 
 
 def reduced(n):
@@ -41,7 +44,7 @@ def test_random_sat_encode(f360, gpu_ctx, oracle):
     enc = f360.SATEncoder(gpu_ctx)
     old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands", "sat.store")}
     try:
-        for case in range(60):
+        for case in range(60 * SCALE):
             w, h = random_geometry(rng)
             bpp = int(rng.choice([3, 4, 4, 4, 5]))
             pad = int(rng.choice([0, 0, 1, 4, 16])) if bpp * w > 8 else 0
@@ -69,7 +72,7 @@ def test_random_sat_encode(f360, gpu_ctx, oracle):
 
 def test_random_sample_interpolate_fused(f360, gpu_ctx, oracle):
     rng = np.random.default_rng(77)
-    for case in range(40):
+    for case in range(40 * SCALE):
         w, h = random_geometry(rng)
         w, h = max(w, 4), max(h, 4)
         if rng.random() < 0.5:
@@ -118,7 +121,7 @@ def test_random_image_sampler_and_gnomonic(f360, gpu_ctx, oracle):
     rng = np.random.default_rng(5)
     proj = f360.Projections(gpu_ctx)
     bad_lp = bad_gn = total_lp = total_gn = 0
-    for case in range(25):
+    for case in range(25 * SCALE):
         w, h = random_geometry(rng)
         w, h = max(w, 4), max(h, 4)
         rw, rh = int(rng.integers(2, w + 40)), int(rng.integers(2, h + 40))
@@ -170,7 +173,7 @@ def test_random_planar_sources(f360, gpu_ctx, oracle):
     enc = f360.SATEncoder(gpu_ctx)
     old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands", "yuv.model")}
     try:
-        for case in range(30):
+        for case in range(30 * SCALE):
             w, h = random_geometry(rng)
             w, h = max(4, w // 4 * 4), max(2, h // 2 * 2)
             model = int(rng.integers(0, 2))
@@ -222,7 +225,7 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
     than a launch holds), pixel formats and gaze points; every frame against the oracle."""
     rng = np.random.default_rng(4242)
     enc = f360.SATEncoder(gpu_ctx)
-    for case in range(24):
+    for case in range(24 * SCALE):
         w, h = random_geometry(rng)
         w, h = max(w, 4), max(h, 4)
         if case % 3 == 0:
