@@ -89,6 +89,7 @@ int expand_common(f360_ctx *ctx, ExpandArgs &a, uint8_t *dst, int dst_w, int dst
   F360_REQUIRE(ctx, "%s: null context", who);
   F360_REQUIRE(dst && src, "%s: null buffer", who);
   F360_REQUIRE(dst_w >= 1 && dst_h >= 1 && src_w >= 1 && src_h >= 1, "%s: bad geometry", who);
+  F360_REQUIRE(f360::dims_ok({dst_w, dst_h, src_w, src_h}), "f360_expand: a dimension exceeds 65536");
   F360_REQUIRE(dst_linesize / dst_w >= 3 && src_linesize / src_w >= 3,
                "%s: linesize gives fewer than 3 bytes per pixel", who);
   F360_REQUIRE(std::fabs(cx) <= 16.0f && std::fabs(cy) <= 16.0f, "%s: gaze centre out of range",

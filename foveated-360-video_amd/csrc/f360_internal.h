@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <initializer_list>
 #include <vector>
 
 #include "f360.h"
@@ -32,6 +33,16 @@ void set_error(const char *fmt, ...);
       return F360_ERR_INVALID_ARG;       \
     }                                    \
   } while (0)
+
+// Upper bound on any frame dimension taken by the entry points that build per-axis tables on the
+// host: the grids are 16-bit offsets (the reference's short2), so nothing larger can be meant,
+// and a wild value must come back as an error code, not as std::bad_alloc through a C boundary.
+constexpr int kMaxDim = 1 << 16;
+inline bool dims_ok(std::initializer_list<int> dims) {
+  for (int d : dims)
+    if (d > kMaxDim) return false;
+  return true;
+}
 
 // Makes `device` the calling thread's current HIP device for the lifetime of the guard and puts
 // the previous one back afterwards: every C-ABI entry that allocates, copies or launches binds

@@ -349,6 +349,7 @@ int f360_is_initialize_grid(f360_image_sampler *is, int target_width,
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 1 &&
                    source_height >= 1,
                "f360_is_initialize_grid: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_is_initialize_grid: a dimension exceeds 65536");
   if (is->gw == target_width && is->gh == target_height && is->sw == source_width &&
       is->sh == source_height && is->gx_dev.p)
     return F360_OK;
@@ -374,6 +375,7 @@ int f360_is_initialize_logpolar_grid(f360_image_sampler *is, int target_width,
   F360_REQUIRE(is, "f360_is_initialize_logpolar_grid: null sampler");
   F360_REQUIRE(target_width >= 1 && target_height >= 1,
                "f360_is_initialize_logpolar_grid: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_is_initialize_logpolar_grid: a dimension exceeds 65536");
   if (is->lw == target_width && is->lh == target_height && is->lrad_dev.p) {
     is->lsw = source_width;
     is->lsh = source_height;
@@ -526,6 +528,7 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
   F360_REQUIRE(target_width >= 2 && target_height >= 2 && source_width >= 1 &&
                    source_height >= 1,
                "f360_is_interpolate_logpolar: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_is_interpolate_logpolar: a dimension exceeds 65536");
   F360_REQUIRE(((uintptr_t)target_dev % 4) == 0 && ((uintptr_t)source_dev % 4) == 0,
                "f360_is_interpolate_logpolar: buffers must be 4-byte aligned");
   F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),

@@ -122,6 +122,7 @@ extern "C" int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_widt
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 1 &&
                    source_height >= 1,
                "f360_gnomonic: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_gnomonic: a dimension exceeds 65536");
   F360_REQUIRE(((uintptr_t)target_dev % 4) == 0 && ((uintptr_t)source_dev % 4) == 0,
                "f360_gnomonic: buffers must be 4-byte aligned");
   F360_REQUIRE(std::fabs(center_x) <= 16.0f && std::fabs(center_y) <= 16.0f,

@@ -807,6 +807,7 @@ int f360_satdec_initialize_grid(f360_sat_decoder *dec, int target_width,
                    source_height >= 2,
                "f360_satdec_initialize_grid: bad geometry %dx%d <- %dx%d",
                target_width, target_height, source_width, source_height);
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_satdec_initialize_grid: a dimension exceeds 65536");
   if (dec->gw == target_width && dec->gh == target_height &&
       dec->sw == source_width && dec->sh == source_height && dec->gx_dev.p)
     return F360_OK;
@@ -889,6 +890,7 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width,
                "f360_satdec_sample_rect: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_satdec_sample_rect: a dimension exceeds 65536");
   F360_REQUIRE(std::fabs(center_x) <= 16.0f && std::fabs(center_y) <= 16.0f,
                "f360_satdec_sample_rect: gaze centre out of range");
   if (!dec->gx_dev.p) {  // src/sat_decoder.cc:312-317
@@ -986,6 +988,7 @@ static int sample_rect_batch_impl(f360_sat_decoder *dec, uint8_t *const *targets
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width,
                "f360_satdec_sample_rect_batch: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_satdec_sample_rect_batch: a dimension exceeds 65536");
   F360_REQUIRE((size_t)source_width * source_height * 12 < ((size_t)1 << 32),
                "f360_satdec_sample_rect_batch: table too large");
   if (!dec->gx_dev.p) {
@@ -1099,6 +1102,7 @@ int foveate_rect_impl(f360_sat_decoder *dec, uint8_t *target_dev, int target_wid
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width,
                "f360_satdec_foveate_rect: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_satdec_foveate_rect: a dimension exceeds 65536");
   F360_REQUIRE(std::fabs(center_x) <= 16.0f && std::fabs(center_y) <= 16.0f,
                "f360_satdec_foveate_rect: gaze centre out of range");
   if (!dec->gx_dev.p) {
@@ -1236,6 +1240,7 @@ int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   F360_REQUIRE(target_width >= 2 && target_height >= 2 && source_width >= 1 &&
                    source_height >= 1,
                "f360_satdec_interpolate_rect: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}), "f360_satdec_interpolate_rect: a dimension exceeds 65536");
   F360_REQUIRE(((uintptr_t)target_dev % 16) == 0 && ((uintptr_t)source_dev % 4) == 0,
                "f360_satdec_interpolate_rect: target must be 16-byte, source 4-byte aligned");
   F360_REQUIRE(std::fabs(center_x) <= 16.0f && std::fabs(center_y) <= 16.0f,

@@ -1353,3 +1353,47 @@ def test_degenerate_reduced_width_grid(f360, gpu_ctx, oracle):
             assert np.array_equal(got, want), (variant, cx, cy)
     gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
     dec.close()
+
+
+def test_wild_arguments_come_back_as_error_codes(f360, gpu_ctx):
+    """Nothing a caller passes may end the process: absurd sizes return an error code (the
+    host-side tables would otherwise throw std::bad_alloc through the C boundary), and the
+    context still works afterwards."""
+    L = f360.lib()
+    big = 2_000_000_000
+    buf = gpu_ctx.malloc(1 << 16)
+    dec, smp, proj = f360.SATDecoder(gpu_ctx), f360.ImageSampler(gpu_ctx), f360.Projections(gpu_ctx)
+    enc = f360.SATEncoder(gpu_ctx)
+    calls = [
+        lambda: dec.InitializeGrid(big, 2, 64, 64),
+        lambda: dec.InitializeGrid(64, 64, big, big),
+        lambda: dec.InitializeGrid(70000, 70000, 70000, 70000),
+        lambda: dec.SampleFrameRectGPU(buf.ptr, big, big, 4, buf.ptr, (64, 64), 0.5, 0.5),
+        lambda: dec.InterpolateFrameRectGPU(buf.ptr, big, big, 4, buf.ptr, 64, 64, 256, 0.5, 0.5),
+        lambda: dec.FoveateFrameRectGPU(buf.ptr, big, 2, 4 * 64, buf.ptr, 64, 64, 256, 0.5, 0.5),
+        lambda: smp.InitializeGrid(big, big, 64, 64),
+        lambda: smp.InitializeLogpolarGrid(big, 3, 64, 64),
+        lambda: smp.InterpolateFrameLogPolarGPU(buf.ptr, big, big, 4, buf.ptr, 64, 64, 256, 0.5, 0.5),
+        lambda: proj.GnomonicProjection(buf.ptr, big, big, 4, buf.ptr, 64, 64, 256, 0.5, 0.5),
+        lambda: gpu_ctx.expand_rect(buf.ptr, big, big, 4, buf.ptr, 64, 64, 256, 0.5, 0.5),
+        lambda: enc.EncodeFrameGPU(buf.ptr, buf.ptr, big, big, 4),
+        lambda: enc.EncodeFrameGPU(buf.ptr, buf.ptr, -5, 7, 4),
+        lambda: enc.EncodeFramesGPU([buf.ptr] * 3, [buf.ptr] * 3, 64, 64, -4),
+        lambda: gpu_ctx.rgb0_to_yuv420p(buf.ptr, buf.ptr, buf.ptr, 8, 4, 4, buf.ptr, 32, big, big),
+    ]
+    for k, call in enumerate(calls):
+        with pytest.raises(f360.F360Error):
+            call()
+        assert L.f360_last_error_string(), k
+    # still alive and correct
+    frame = np.arange(16 * 8 * 4, dtype=np.uint8).reshape(8, 64)
+    src = gpu_ctx.upload(frame)
+    sat = gpu_ctx.malloc(16 * 8 * 12)
+    enc.EncodeFrameGPU(sat.ptr, src.ptr, 16, 8, 64)
+    got = sat.copy_to_host(np.uint32, (8, 16, 3))
+    px = frame.reshape(8, 16, 4)[:, :, :3].astype(np.uint64)
+    assert np.array_equal(got, px.cumsum(0).cumsum(1).astype(np.uint32))
+    for b in (buf, src, sat):
+        b.free()
+    dec.close()
+    smp.close()

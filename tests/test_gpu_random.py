@@ -258,3 +258,35 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
             b.free()
         dec.close()
     gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
+
+
+def test_random_output_colour_step(f360, gpu_ctx, oracle):
+    """f360_rgb0_to_yuv420p on random even sizes (8 rows up), row paddings of the source and of
+    each plane, unaligned bases, both libswscale models; bytes outside the planes untouched."""
+    rng = np.random.default_rng(99)
+    for case in range(30 * SCALE):
+        w = 2 * int(rng.integers(1, 700)) if case % 3 else 8 * int(rng.integers(1, 300))
+        h = 2 * int(rng.integers(4, 150))
+        model = int(rng.integers(0, 2))
+        spad = int(rng.choice([0, 0, 4, 16, 20]))
+        pads = tuple(int(rng.choice([0, 0, 1, 4, 8, 12])) for _ in range(3))
+        off = int(rng.choice([0, 0, 4, 16]))
+        src_h = rng.integers(0, 256, (h, 4 * w + spad), dtype=np.uint8)
+        if case % 5 == 0:
+            src_h[:] = rng.choice([0, 255])
+        want = oracle.rgb0_to_yuv420p(src_h, w, h, model, pads=pads)
+        gpu_ctx.set_option("yuv.model", model)
+        raw = np.zeros(src_h.size + 64, dtype=np.uint8)
+        raw[off:off + src_h.size] = src_h.reshape(-1)
+        src = gpu_ctx.upload(raw)
+        planes = [gpu_ctx.malloc(p.size) for p in want]
+        for p in planes:
+            p.fill(0xEE)
+        gpu_ctx.rgb0_to_yuv420p(planes[0].ptr, planes[1].ptr, planes[2].ptr, want[0].shape[1],
+                                want[1].shape[1], want[2].shape[1], src.ptr + off, src_h.shape[1],
+                                w, h)
+        for name, buf, ref in zip("yuv", planes, want):
+            assert np.array_equal(buf.copy_to_host(np.uint8, ref.shape), ref), (case, name, w, h, model, spad, pads, off)
+            buf.free()
+        src.free()
+    gpu_ctx.set_option("yuv.model", 1)
