@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="print the launch command and the per-rank frame ranges; no GPU call")
     ap.add_argument("--frames-per-call", type=int, default=8,
-                    help="two-call path: N frames per EncodeFramesGPU call (N single calls from planes), then one "
+                    help="two-call path: N frames per EncodeFramesGPU / EncodeFramesYUV420PGPU call, then one "
                          "SampleFramesRectGPU call for their N tables (the frames share launches: "
                          "the encoder as many as stay cache-resident between its two reads -- one "
                          "at 8K --, the sampler all N); 1 = EncodeFrameGPU + SampleFrameRectGPU "
@@ -273,10 +273,9 @@ def main():
             calls[0] += 1
             sampled = profile and calls[0] % args.profile_every == 1
             if sampled:
-                ctxs[0].profile_arm(1 + n if yuv else 2)
-            if yuv:  # no batched entry for planes: n single encodes, then the shared sample
-                for i in range(n):
-                    encs[0].EncodeFrameYUV420PGPU(sat_ptr[i], *yuv_ptr[g + i], w, w // 2, w // 2, w, h)
+                ctxs[0].profile_arm(2)
+            if yuv:
+                encs[0].EncodeFramesYUV420PGPU(sat_ptr[:n], yuv_ptr[g:g + n], w, w // 2, w // 2, w, h)
             else:
                 encs[0].EncodeFramesGPU(sat_ptr[:n], frame_ptr[g:g + n], w, h, 4 * w)
             decs[0].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n], (w, h),

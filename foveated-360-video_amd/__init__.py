@@ -90,6 +90,9 @@ _SIGNATURES = {
     "f360_sat_encode_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
                                       c_int, c_int]),
     "f360_sat_encode_batch_max": (c_int, []),
+    "f360_sat_encode_yuv420p_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                              POINTER(c_void_p), POINTER(c_void_p), c_int, c_int,
+                                              c_int, c_int, c_int]),
     "f360_yuv420p_to_rgb0": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int]),
     "f360_rgb0_to_yuv420p": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -385,6 +388,24 @@ class SATEncoder:
         srcs = (c_void_p * n)(*[int(p) for p in cl_source_buffers])
         _check(lib().f360_sat_encode_batch(self.cl_manager.handle, n, sats, srcs, source_width,
                                            source_height, source_linesize))
+
+    def EncodeFramesYUV420PGPU(self, cl_target_buffers, planes, y_linesize: int, u_linesize: int,
+                               v_linesize: int, source_width: int, source_height: int) -> None:
+        """EncodeFrameYUV420PGPU for several frames in shared launches; `planes` is a list of
+        (y, u, v) device pointers, one per table.  Not in the reference."""
+        if self.cl_manager is None:
+            raise F360Error(F360_ERR_NOT_INITIALIZED,
+                            "[SATEncoder::EncodeFramesYUV420PGPU] Not initialized with OpenCL")
+        n = len(cl_target_buffers)
+        if n != len(planes):
+            raise ValueError("EncodeFramesYUV420PGPU: as many tables as plane triples")
+        sats = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        ys = (c_void_p * n)(*[int(p[0]) for p in planes])
+        us = (c_void_p * n)(*[int(p[1]) for p in planes])
+        vs = (c_void_p * n)(*[int(p[2]) for p in planes])
+        _check(lib().f360_sat_encode_yuv420p_batch(self.cl_manager.handle, n, sats, ys, us, vs,
+                                                   y_linesize, u_linesize, v_linesize,
+                                                   source_width, source_height))
 
     def EncodeFrameYUV420PGPU(self, cl_target_buffer, cl_y, cl_u, cl_v, y_linesize: int,
                               u_linesize: int, v_linesize: int, source_width: int,

@@ -144,6 +144,7 @@ struct f360_ctx {
   int opt_stream_rows = 8;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64
   int opt_stream_depth = 2;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 3 | 5)
   int opt_stream_spread = 0;   // "sample.spread": consecutive streamer waves take tiles a quarter of the row apart instead of neighbouring ones
+  int opt_batch_mb = 180;      // "sat.batch_mb": source bytes (MB) a batched encoder launch may cover
   int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
@@ -223,12 +224,13 @@ struct SatEmit {
 };
 // `yuv` non-null: the pixels come from three planes (src_dev / linesize unused)
 // `count` > 0: a batch of frames of one geometry (tables sats[k] of sources srcs[k]; sat_dev /
-// src_dev unused, no emit, no planes).  `profile`: -1 = take a profile slot if one is armed,
+// src_dev unused, no emit; `yuvs` non-null: frame k's planes, all with yuvs[0]'s linesizes).  `profile`: -1 = take a profile slot if one is armed,
 // 0 / 1 = the caller already decided (one slot per batched call, however many launches)
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
                     int count = 0, uint32_t *const *sats = nullptr,
-                    const uint8_t *const *srcs = nullptr, int profile = -1);
+                    const uint8_t *const *srcs = nullptr, int profile = -1,
+                    const YuvPlanes *yuvs = nullptr);
 }  // namespace f360
 
 struct f360_event {

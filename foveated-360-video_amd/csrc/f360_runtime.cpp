@@ -259,6 +259,7 @@ static const OptionSlot kOptions[] = {
     {"sample.depth", &f360_ctx::opt_stream_depth},
     {"sample.spread", &f360_ctx::opt_stream_spread},
     {"sample.groups", &f360_ctx::opt_stream_groups},
+    {"sat.batch_mb", &f360_ctx::opt_batch_mb},
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},

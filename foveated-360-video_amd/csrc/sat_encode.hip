@@ -23,6 +23,7 @@
 //   Total HBM traffic ~20.6 B/px against 16 B/px compulsory (the reference's
 //   three passes move 64 B/px).
 #include <algorithm>
+#include <vector>
 
 #include "f360_internal.h"
 #include "fov_maps.h"
@@ -159,8 +160,9 @@ struct EncodeArgs {
 // (a kernel argument of its own: inside EncodeArgs the arrays keep the compiler from taking
 // that struct apart, it lands in scratch memory and the row loops wait on vmcnt(0))
 struct EncodeBatch {
-  const uint8_t *src[kEncBatch];
+  const uint8_t *src[kEncBatch];  // packed source, or the luma plane
   uint32_t *sat[kEncBatch];
+  const uint8_t *u[kEncBatch], *v[kEncBatch];  // planar sources
 };
 
 // What a workgroup works on: the call's one frame, or frame blockIdx.y of a batch.
@@ -168,19 +170,25 @@ struct EncodeFrame {
   const uint8_t *src;
   uint32_t *sat;
   size_t ws;  // offset of the frame's scratch slice, in elements
+  const uint8_t *y, *u, *v;  // planar sources (linesizes are the call's, in EncodeArgs::yuv)
 };
 // Constant indices and scalar selects: a dynamic index into a by-value argument makes the
 // compiler copy it to scratch memory.
 #define F360_ENCODE_FRAME(fr, a, b)                                          \
-  EncodeFrame fr{a.src, a.sat, 0};                                           \
+  EncodeFrame fr{a.src, a.sat, 0, a.yuv.y, a.yuv.u, a.yuv.v};                \
   if (a.nbatch != 0) {                                                       \
     const int f_ = (int)blockIdx.y;                                          \
     fr.src = b.src[0];                                                       \
     fr.sat = b.sat[0];                                                       \
+    fr.u = b.u[0];                                                           \
+    fr.v = b.v[0];                                                           \
     _Pragma("unroll") for (int k_ = 1; k_ < kEncBatch; ++k_) if (f_ == k_) { \
       fr.src = b.src[k_];                                                    \
       fr.sat = b.sat[k_];                                                    \
+      fr.u = b.u[k_];                                                        \
+      fr.v = b.v[k_];                                                        \
     }                                                                        \
+    fr.y = fr.src;                                                           \
     fr.ws = (size_t)f_ * a.ws_stride;                                        \
   }
 
@@ -215,21 +223,21 @@ __device__ __forceinline__ void batch_pixels(const EncodeArgs &a, const RowBatch
 // (odd: the last row of the frame or of the caller's run of rows) re-read that row -- what lies
 // past it is masked or never stored by the callers
 template <int SRC>
-__device__ __forceinline__ void load_yuv_batch(const EncodeArgs &a, RowBatch<SRC> &b, int y,
-                                               int x0, int y_last) {
+__device__ __forceinline__ void load_yuv_batch(const EncodeArgs &a, const EncodeFrame &fr,
+                                               RowBatch<SRC> &b, int y, int x0, int y_last) {
   if constexpr (SRC >= kSrcYuvSwsC) {
     const int xc = min(x0, a.width - kLanePx);
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r)
       b.y4[r] = *reinterpret_cast<const uint32_t *>(
-          a.yuv.y + (size_t)min(y + r, y_last) * a.yuv.y_linesize + xc);
+          fr.y + (size_t)min(y + r, y_last) * a.yuv.y_linesize + xc);
 #pragma unroll
     for (int r = 0; r < kRowUnroll / 2; ++r) {
       const size_t crow = (size_t)min((y >> 1) + r, y_last >> 1);
       const uint32_t u =
-          *reinterpret_cast<const uint16_t *>(a.yuv.u + crow * a.yuv.u_linesize + (xc >> 1));
+          *reinterpret_cast<const uint16_t *>(fr.u + crow * a.yuv.u_linesize + (xc >> 1));
       const uint32_t v =
-          *reinterpret_cast<const uint16_t *>(a.yuv.v + crow * a.yuv.v_linesize + (xc >> 1));
+          *reinterpret_cast<const uint16_t *>(fr.v + crow * a.yuv.v_linesize + (xc >> 1));
       b.uv[r] = u | (v << 16);
     }
   }
@@ -303,7 +311,7 @@ template <int SRC>
 __device__ __forceinline__ void reduce_load_batch(const EncodeArgs &a, const EncodeFrame &fr,
                                                   RowBatch<SRC> &b, int y, int x0, int y_last) {
   if constexpr (SRC >= kSrcYuvSwsC) {
-    load_yuv_batch<SRC>(a, b, y, x0, y_last);
+    load_yuv_batch<SRC>(a, fr, b, y, x0, y_last);
   } else if constexpr (SRC == kSrcRgb0) {
     // branch-free: rows past the wave's last row re-read that row (a cache hit), validity is
     // applied by the caller's masks
@@ -837,16 +845,28 @@ namespace f360 {
 
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
-                    int count, uint32_t *const *sats, const uint8_t *const *srcs, int profile) {
+                    int count, uint32_t *const *sats, const uint8_t *const *srcs, int profile,
+                    const YuvPlanes *yuvs) {
   F360_REQUIRE(ctx, "f360_sat_encode: null context");
   F360_BIND_DEVICE(ctx);
   if (count > 0) {
-    F360_REQUIRE(count <= kEncBatch && sats && srcs && !emit && !yuv,
+    F360_REQUIRE(count <= kEncBatch && sats && (srcs || yuvs) && !emit && !yuv,
                  "f360_sat_encode_batch: count %d outside 1..%d, or null arrays", count, kEncBatch);
-    for (int k = 0; k < count; ++k)
-      F360_REQUIRE(sats[k] && srcs[k], "f360_sat_encode_batch: null buffer %d", k);
+    for (int k = 0; k < count; ++k) {
+      F360_REQUIRE(sats[k] && (yuvs ? yuvs[k].y && yuvs[k].u && yuvs[k].v : srcs[k] != nullptr),
+                   "f360_sat_encode_batch: null buffer %d", k);
+      if (yuvs)  // one set of linesizes and alignments for the whole launch
+        F360_REQUIRE(yuvs[k].y_linesize == yuvs[0].y_linesize &&
+                         yuvs[k].u_linesize == yuvs[0].u_linesize &&
+                         yuvs[k].v_linesize == yuvs[0].v_linesize &&
+                         ((uintptr_t)yuvs[k].y % 4) == 0 && ((uintptr_t)yuvs[k].u % 2) == 0 &&
+                         ((uintptr_t)yuvs[k].v % 2) == 0 && ((uintptr_t)sats[k] % 16) == 0,
+                     "f360_sat_encode_yuv420p_batch: frame %d: other linesizes than frame 0, "
+                     "or a misaligned plane / table", k);
+    }
     sat_dev = sats[0];
-    src_dev = srcs[0];
+    if (yuvs) yuv = &yuvs[0];
+    else src_dev = srcs[0];
   }
   F360_REQUIRE((sat_dev || emit) && (src_dev || yuv), "f360_sat_encode: null buffer");
   F360_REQUIRE(width >= 1 && height >= 1, "f360_sat_encode: bad size %dx%d", width,
@@ -914,15 +934,18 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   a.ws_stride = p.ws_stride;
   EncodeBatch eb;
   for (int k = 0; k < kEncBatch; ++k) {
-    eb.src[k] = count > 0 ? srcs[k < count ? k : 0] : nullptr;
-    eb.sat[k] = count > 0 ? sats[k < count ? k : 0] : nullptr;
+    const int q = k < count ? k : 0;
+    eb.src[k] = count <= 0 ? nullptr : yuvs ? yuvs[q].y : srcs[q];
+    eb.sat[k] = count > 0 ? sats[q] : nullptr;
+    eb.u[k] = count > 0 && yuvs ? yuvs[q].u : nullptr;
+    eb.v[k] = count > 0 && yuvs ? yuvs[q].v : nullptr;
   }
   const unsigned frames = count > 0 ? (unsigned)count : 1u;
 
   const bool prof = profile < 0 ? f360::take_profile_slot(ctx) : profile != 0;
   bool vec = !yuv && bpp == 4 && (width % 4) == 0 && (linesize % 16) == 0 &&
              ((uintptr_t)src_dev % 16) == 0 && (emit || ((uintptr_t)sat_dev % 16) == 0);
-  for (int k = 1; k < count; ++k)  // one kernel flavour for the whole batch
+  for (int k = 1; k < count && !yuvs; ++k)  // one kernel flavour for the whole batch
     vec = vec && ((uintptr_t)srcs[k] % 16) == 0 && ((uintptr_t)sats[k] % 16) == 0;
   const int yuv_src = !yuv ? 0 : ctx->opt_yuv_model == 1 ? kSrcYuvSwsX86 : kSrcYuvSwsC;
   const dim3 block(64 * kWavesPerBlock);
@@ -933,11 +956,11 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   {
     f360::KernelSpan span(ctx, f360::kSatReduce, prof, (int)frames);
     if (yuv_src == kSrcYuvSwsX86)
-      hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsX86>, dim3(blocks1), block, 0,
+      hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsX86>, dim3(blocks1, frames), block, 0,
                          ctx->stream, a, eb);
     else if (yuv_src == kSrcYuvSwsC)
-      hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsC>, dim3(blocks1), block, 0, ctx->stream,
-                         a, eb);
+      hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsC>, dim3(blocks1, frames), block, 0,
+                         ctx->stream, a, eb);
     else if (vec)
       hipLaunchKernelGGL(sat_reduce_kernel<kSrcRgb0>, dim3(blocks1, frames), block, 0, ctx->stream, a, eb);
     else
@@ -999,20 +1022,51 @@ extern "C" int f360_sat_encode_batch(f360_ctx *ctx, int count, uint32_t *const *
                                      int linesize) {
   F360_REQUIRE(count >= 1 && sat_dev && src_dev && width >= 1 && height >= 1 && linesize >= 1,
                "f360_sat_encode_batch: bad arguments");
-  // Frames per launch.  The frames of a launch are read twice, by the reducer and then by the
-  // table writer, and the second read comes out of the 256 MiB Infinity Cache only while they
-  // fit beside the rest of the traffic: with two or more 8K frames (118 MB each) per launch the
-  // writer takes 87-95 us per frame instead of 75.  Sixteen 1080p frames (133 MB) are fine and
-  // 2.5 times faster than one at a time.
+  // Frames per launch ("sat.batch_mb", 180 MB of source).  The frames of a launch are read
+  // twice, by the reducer and then by the table writer, and the second read comes out of the
+  // 256 MiB Infinity Cache only while they fit beside the rest of the traffic: two 8K RGB0
+  // frames (236 MB) per launch and the writer takes 85-87 us per frame instead of 75, whereas
+  // four 8K frames from planes (176 MB) keep it at 74 and six (264 MB) do not (80).  Sixteen
+  // 1080p frames (133 MB) are 2.7 times faster than one at a time.
   const size_t frame_bytes = (size_t)linesize * height;
   const int per_launch = (int)std::min<size_t>(
-      std::max<size_t>(((size_t)144 << 20) / frame_bytes, 1), (size_t)f360_sat_encode_batch_max());
+      std::max<size_t>(((size_t)std::max(ctx ? ctx->opt_batch_mb : 180, 1) << 20) / frame_bytes, 1),
+      (size_t)f360_sat_encode_batch_max());
   F360_REQUIRE(ctx, "f360_sat_encode_batch: null context");
   const int prof = f360::take_profile_slot(ctx) ? 1 : 0;  // one slot for the whole call
   for (int k = 0; k < count; k += per_launch) {
     const int n = std::min(count - k, per_launch);
     const int st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr,
                                          nullptr, n, sat_dev + k, src_dev + k, prof);
+    if (st != F360_OK) return st;
+  }
+  return F360_OK;
+}
+
+extern "C" int f360_sat_encode_yuv420p_batch(f360_ctx *ctx, int count, uint32_t *const *sat_dev,
+                                             const uint8_t *const *y_dev,
+                                             const uint8_t *const *u_dev,
+                                             const uint8_t *const *v_dev, int y_linesize,
+                                             int u_linesize, int v_linesize, int width,
+                                             int height) {
+  F360_REQUIRE(ctx && count >= 1 && sat_dev && y_dev && u_dev && v_dev && width >= 1 &&
+                   height >= 1 && y_linesize >= 1,
+               "f360_sat_encode_yuv420p_batch: bad arguments");
+  // frames per launch: the same cache budget as f360_sat_encode_batch, on 1.5 bytes per pixel
+  // (8K: four frames per launch -- reducer 31 -> 23 us and carry pass 7.4 -> 3 us per frame)
+  const size_t frame_bytes = (size_t)y_linesize * height * 3 / 2;
+  const int per_launch = (int)std::min<size_t>(
+      std::max<size_t>(((size_t)std::max(ctx->opt_batch_mb, 1) << 20) / frame_bytes, 1),
+      (size_t)kEncBatch);
+  const int prof = f360::take_profile_slot(ctx) ? 1 : 0;  // one slot for the whole call
+  std::vector<f360::YuvPlanes> planes((size_t)count);
+  for (int k = 0; k < count; ++k)
+    planes[(size_t)k] = f360::YuvPlanes{y_dev[k], u_dev[k], v_dev[k], y_linesize, u_linesize,
+                                        v_linesize};
+  for (int k = 0; k < count; k += per_launch) {
+    const int n = std::min(count - k, per_launch);
+    const int st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, 0, nullptr, nullptr,
+                                         n, sat_dev + k, nullptr, prof, planes.data() + k);
     if (st != F360_OK) return st;
   }
   return F360_OK;

@@ -144,14 +144,20 @@ int f360_sat_encode_yuv420p(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *y_d
  * is what small frames need: a 1080p frame alone cannot fill the device and its three launches
  * cost more than its traffic (16 per launch: 2.5 times the throughput).  The call splits into
  * launches of as many frames as stay cache-resident between the encoder's two reads of them
- * (about 144 MB of source, at most f360_sat_encode_batch_max() = 16: one 8K frame, four
- * 3840x1920 frames, sixteen 1080p frames).  Not in the
+ * (about 180 MB of source, at most f360_sat_encode_batch_max() = 16: one 8K RGB0 frame or four
+ * 8K frames from planes, six 3840x1920 frames, sixteen 1080p frames).  Not in the
  * reference, whose encoder handles one frame per call (src/sat_encoder.cc:67-135); a server
  * that holds several decoded frames, or several connections on one GPU, can use it.  The
  * encoder's scratch grows to `count` frames' worth (17 MB per 8K frame). */
 int f360_sat_encode_batch(f360_ctx *ctx, int count, uint32_t *const *sat_dev,
                           const uint8_t *const *src_dev, int width, int height, int linesize);
 int f360_sat_encode_batch_max(void);
+/* The same from planes: f360_sat_encode_yuv420p for `count` frames that share their three
+ * linesizes (frames of one decoder do).  HOST arrays of device pointers. */
+int f360_sat_encode_yuv420p_batch(f360_ctx *ctx, int count, uint32_t *const *sat_dev,
+                                  const uint8_t *const *y_dev, const uint8_t *const *u_dev,
+                                  const uint8_t *const *v_dev, int y_linesize, int u_linesize,
+                                  int v_linesize, int width, int height);
 
 /* ---- SATDecoder --------------------------------------------------------- */
 int f360_satdec_create(f360_ctx *ctx, f360_sat_decoder **out);

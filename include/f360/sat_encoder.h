@@ -54,6 +54,26 @@ class SATEncoder {
                 << f360_last_error_string() << std::endl;
   }
 
+  // The same from a decoder's planes (frames of one decoder share their linesizes).
+  void EncodeFramesYUV420PGPU(int count, cl_mem const *cl_target_buffers, cl_mem const *cl_y,
+                              cl_mem const *cl_u, cl_mem const *cl_v, int y_linesize,
+                              int u_linesize, int v_linesize, int source_width,
+                              int source_height) {
+    if (!use_OpenCL) {
+      std::cerr << "[SATEncoder::EncodeFramesYUV420PGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_sat_encode_yuv420p_batch(
+        cl_manager->context.get(), count, reinterpret_cast<uint32_t *const *>(cl_target_buffers),
+        reinterpret_cast<const uint8_t *const *>(cl_y),
+        reinterpret_cast<const uint8_t *const *>(cl_u),
+        reinterpret_cast<const uint8_t *const *>(cl_v), y_linesize, u_linesize, v_linesize,
+        source_width, source_height);
+    if (ret != F360_OK)
+      std::cerr << "[SATEncoder::EncodeFramesYUV420PGPU] kernel launch failed:" << ret << " "
+                << f360_last_error_string() << std::endl;
+  }
+
   // src/sat_encoder.cc:137-185: the same table on the host (uint32 [height][width][3]).
   template <class CodecContext, class Frame>
   void EncodeFrameCPU(uint32_t *target_frame, CodecContext *codec_ctx, Frame *frame) {

@@ -1397,3 +1397,28 @@ def test_wild_arguments_come_back_as_error_codes(f360, gpu_ctx):
         b.free()
     dec.close()
     smp.close()
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("w,h,pad,n", [(256, 64, (0, 0, 0), 3), (260, 38, (4, 2, 6), 5),
+                                       (1920, 1080, (0, 0, 0), 2), (64, 16, (0, 0, 0), 19)])
+def test_sat_encode_yuv420p_batch_matches_oracle(f360, gpu_ctx, oracle, model, w, h, pad, n):
+    """Planar frames in shared launches: every table equals the oracle table of the
+    oracle-converted frame (both libswscale models; 19 frames: more than one launch)."""
+    gpu_ctx.set_option("yuv.model", model)
+    planes = [yuv_planes(w, h, 70 + k, pad) for k in range(n)]
+    dev = [tuple(gpu_ctx.upload(p) for p in pl) for pl in planes]
+    sats = [gpu_ctx.malloc(w * h * 12) for _ in range(n)]
+    for s in sats:
+        s.fill(0xEE)
+    y0, u0, v0 = planes[0]
+    f360.SATEncoder(gpu_ctx).EncodeFramesYUV420PGPU(
+        [s.ptr for s in sats], [(a.ptr, b.ptr, c.ptr) for (a, b, c) in dev], y0.shape[1],
+        u0.shape[1], v0.shape[1], w, h)
+    for k in range(n):
+        y, u, v = planes[k]
+        want = oracle.sat_encode(oracle.yuv420p_to_rgb0(y, u, v, w, h, model), w, h, 4 * w)
+        assert np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want), k
+    gpu_ctx.set_option("yuv.model", 1)
+    for b in sats + [p for t in dev for p in t]:
+        b.free()
