@@ -98,6 +98,10 @@ struct SatEncodePlan {
   uint32_t *rowcarry = nullptr;  // [nstrips][height][3] sum of the strips to the left
   uint32_t *tiletotal = nullptr; // [nstrips][nbands][3]
   uint32_t *tprefix = nullptr;   // [nstrips][nbands][3] sum of the tiles to the left
+  // read-once batched encoder (sat_walk_kernel): hand-off granules, the launch state words
+  // (device memory, advanced by the launches themselves) and the host-mapped error word
+  DevBuf walk_chain, walk_state;
+  uint32_t *walk_err_host = nullptr, *walk_err_dev = nullptr;
 };
 
 }  // namespace f360
@@ -108,6 +112,7 @@ enum KernelId {
   kSatReduce = 0,
   kSatCarry,
   kSatWrite,
+  kSatWalk,
   kSampleRect,
   kInterpolateRect,
   kSatDecode,
@@ -145,6 +150,9 @@ struct f360_ctx {
   int opt_stream_depth = 2;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 3 | 5)
   int opt_stream_spread = 0;   // "sample.spread": consecutive streamer waves take tiles a quarter of the row apart instead of neighbouring ones
   int opt_batch_mb = 180;      // "sat.batch_mb": source bytes (MB) a batched encoder launch may cover
+  int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows
+  int opt_walk_units = 960;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder
+  int opt_walk_depth = 2;      // "sat.walk_depth": 8-row batches a strip owner rotates through (2 | 3 | 4)
   int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size

@@ -109,6 +109,9 @@ int f360_ctx_destroy(f360_ctx *ctx) {
   f360::DeviceGuard guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->enc.ws.release();
+  ctx->enc.walk_chain.release();
+  ctx->enc.walk_state.release();
+  if (ctx->enc.walk_err_host) (void)hipHostFree(ctx->enc.walk_err_host);
   ctx->ex_tables.release();
   ctx->gn_table.release();
   ctx->ex_keys.release();
@@ -138,6 +141,13 @@ int f360_sync(f360_ctx *ctx) {
   F360_REQUIRE(ctx, "f360_sync: null context");
   F360_BIND_DEVICE(ctx);
   F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // the read-once encoder's hand-off waits are bounded; one that ran into its bound says so here
+  if (ctx->enc.walk_err_host && *ctx->enc.walk_err_host) {
+    *ctx->enc.walk_err_host = 0;
+    set_error("f360_sat_encode_batch: a strip hand-off of the read-once encoder timed out; "
+              "the tables of that call are invalid");
+    return F360_ERR_HIP;
+  }
   return F360_OK;
 }
 
@@ -260,6 +270,9 @@ static const OptionSlot kOptions[] = {
     {"sample.spread", &f360_ctx::opt_stream_spread},
     {"sample.groups", &f360_ctx::opt_stream_groups},
     {"sat.batch_mb", &f360_ctx::opt_batch_mb},
+    {"sat.walk", &f360_ctx::opt_walk},
+    {"sat.walk_units", &f360_ctx::opt_walk_units},
+    {"sat.walk_depth", &f360_ctx::opt_walk_depth},
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
@@ -289,6 +302,12 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
       if (s.field == &f360_ctx::opt_stream_depth)
         F360_REQUIRE(value == 2 || value == 3 || value == 5, "sample.depth must be 2, 3 or 5: %d",
                      value);
+      if (s.field == &f360_ctx::opt_walk)
+        F360_REQUIRE(value >= -1 && value <= 1, "sat.walk must be -1 (automatic), 0 or 1: %d", value);
+      if (s.field == &f360_ctx::opt_walk_depth)
+        F360_REQUIRE(value >= 2 && value <= 4, "sat.walk_depth must be 2, 3 or 4: %d", value);
+      if (s.field == &f360_ctx::opt_walk_units)
+        F360_REQUIRE(value >= 1, "sat.walk_units must be >= 1: %d", value);
       if (s.field == &f360_ctx::opt_sample_variant)
         F360_REQUIRE(value >= 0 && value <= 2, "sample.variant must be 0, 1 or 2: %d", value);
       ctx->*(s.field) = value;
@@ -311,6 +330,7 @@ int f360_ctx_get_option(const f360_ctx *ctx, const char *key, int *value) {
 
 static const char *const kKernelNames[f360::kKernelCount] = {
     "sat_reduce_kernel",        "sat_carry_kernel",       "sat_write_kernel",
+    "sat_walk_kernel",
     "sample_rect_kernel",       "interpolate_rect_kernel", "decode_kernel",
     "is_sample_rect_kernel",    "is_sample_logpolar_kernel",
     "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel",

@@ -521,9 +521,9 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
                                  int source_linesize, float center_x,
                                  float center_y) {
   (void)target_linesize;
-  F360_BIND_DEVICE(is->ctx);
   (void)source_linesize;
   F360_REQUIRE(is, "f360_is_interpolate_logpolar: null sampler");
+  F360_BIND_DEVICE(is->ctx);
   F360_REQUIRE(target_dev && source_dev, "f360_is_interpolate_logpolar: null buffer");
   F360_REQUIRE(target_width >= 2 && target_height >= 2 && source_width >= 1 &&
                    source_height >= 1,
@@ -588,9 +588,9 @@ int f360_is_logpolar_gaussian_blur(f360_image_sampler *is, uint8_t *target_dev,
                                    int target_width, int target_height,
                                    int target_linesize,
                                    const uint8_t *source_dev) {
-  (void)target_linesize;
-  F360_BIND_DEVICE(is->ctx);  // kernel indexes 4-byte texels with a row stride of width
+  (void)target_linesize;  // kernel indexes 4-byte texels with a row stride of width
   F360_REQUIRE(is, "f360_is_logpolar_gaussian_blur: null sampler");
+  F360_BIND_DEVICE(is->ctx);
   F360_REQUIRE(target_dev && source_dev, "f360_is_logpolar_gaussian_blur: null buffer");
   F360_REQUIRE(target_width >= 1 && target_height >= 1,
                "f360_is_logpolar_gaussian_blur: bad geometry");

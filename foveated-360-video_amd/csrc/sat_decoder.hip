@@ -927,11 +927,13 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   const int variant = ctx->opt_sample_variant;
   const bool can_stream = tile_stream_applies(dec, sat_dev, source_width, source_height,
                                               target_linesize, target_height);
+  // host-side checks first: the span's start event must sit right in front of the launch
+  const bool fits = variant == 2 && can_stream &&
+                    tile_stream_fits(dec, cxp, source_width, target_width);
   f360::KernelSpan span(ctx, f360::kSampleRect, f360::take_profile_slot(ctx));
   bool streamed = false;
   if (variant == 2 && can_stream) {
     const int ntiles = (source_width + kTsTile - 1) / kTsTile;
-    const bool fits = tile_stream_fits(dec, cxp, source_width, target_width);
     if (fits) {
       const int rows = std::min(ctx->opt_stream_rows, kTsMaxRows);
       const int nblocks = (target_height + rows - 1) / rows;

@@ -156,6 +156,12 @@ struct EncodeArgs {
   // scratch arrays (frame f's start f * ws_stride elements after frame 0's)
   int nbatch;
   size_t ws_stride;
+  // read-once batched encoder (sat_walk_kernel): (frame, strip) units of the launch, 8-row
+  // batches per strip, and the hand-off state (see WalkState)
+  int walk_units, walk_nbatches;
+  struct WalkState *walk;
+  unsigned long long *walk_chain;  // [unit][batch][24] {tag:40 | row prefix:24}
+  uint32_t *walk_err;              // host-visible: a hand-off wait ran into its bound
 };
 // (a kernel argument of its own: inside EncodeArgs the arrays keep the compiler from taking
 // that struct apart, it lands in scratch memory and the row loops wait on vmcnt(0))
@@ -762,6 +768,237 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   }
 }
 
+// ---- read-once batched encoder: strip owners walk down their frames --------------
+// f360_sat_encode_batch with enough frames to fill the device.  One wave owns a 256-pixel strip
+// of ONE frame and walks all its rows top to bottom: the vertical running sums never leave its
+// registers, the strip-local row prefix is the DPP scan of the table writer, and the only thing
+// a strip needs from outside is, per row, the sum of that row over the strips to its left
+// (3 dwords).  That prefix travels left to right from strip to strip through global memory:
+// per batch of 8 rows a strip reads its left neighbour's 24 running row prefixes, adds its own
+// 24 row sums and publishes the result for its right neighbour BEFORE it does the heavy part
+// (scan results are kept in registers), so the chain advances at hand-off latency, not at
+// table-writing speed.  The frame is read once: no reducer pass, no carry kernel
+// (sat_encoder_encode_kernels.cl:44-74 done in one pass over the pixels).
+//
+// Hand-off (MI355X_MICROARCH.md "Workgroup dispatch ... visibility", form R2): the payload IS
+// the flag.  A granule is one naturally aligned 8-byte word {tag: 40 bits | row prefix: 24
+// bits} written by one lane with ONE sc1 (write-through) store and polled with sc1 loads that
+// bypass the reader's L1; the tag is the launch's serial number, so entries of earlier launches
+// never match and nothing is cleared between launches.  A row prefix is < 65536 * 255 < 2^24.
+// No fence, no release, no acquire: a granule is either this launch's (tag matches) or not yet.
+//
+// Forward progress: workgroups draw a ticket (atomic counter) and unit = ticket order, frames
+// major, strips left to right.  A strip only ever waits for the unit one ticket position before
+// it, whose workgroup drew its ticket earlier, i.e. is resident and running; strip 0 of a frame
+// waits for nobody.  Every wait is bounded (kWalkSpinLimit polls); a wave that runs into the
+// bound raises *walk_err (host-mapped, checked by f360_sync) and stops waiting, so the grid
+// always drains.  The state words live in device memory and are advanced by the launch itself
+// (the last wave to retire zeroes the ticket and bumps the serial), so nothing per launch
+// comes from the host: a captured launch replays correctly.
+struct WalkState {
+  uint32_t ticket;            // workgroups of the current launch that have started
+  uint32_t done;              // waves of the current launch that have retired
+  unsigned long long serial;  // launch number = tag of this launch's granules; never 0
+};
+constexpr int kWalkFrames = 64;              // frames per launch
+constexpr int kWalkLanes = 3 * kRowUnroll;   // granules per batch: 8 rows x 3 channels
+constexpr uint32_t kWalkSpinLimit = 1u << 20;
+constexpr unsigned long long kWalkTagMask = (1ull << 40) - 1;
+
+struct WalkBatch {
+  const uint8_t *src[kWalkFrames];  // packed source, or the luma plane
+  uint32_t *sat[kWalkFrames];
+  const uint8_t *u[kWalkFrames], *v[kWalkFrames];  // planar sources
+};
+
+// v[lane] = s (a wave-uniform value) for one constant lane
+__device__ __forceinline__ void walk_writelane(uint32_t &v, uint32_t s, int lane) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(lane));
+}
+
+__device__ __forceinline__ void walk_store_granule(unsigned long long *p, unsigned long long g) {
+  // one lane, one 8-byte write-through store; hidden from the compiler's vmcnt bookkeeping
+  // like the table stores (global_store_b128_uncounted)
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(g) : "memory");
+}
+
+// The slow path of a hand-off wait: the first poll (issued a batch's worth of scans earlier)
+// did not find this launch's tag in all 24 granules.  Self-contained asm loads with their own
+// full wait, so the compiler's count of the pixel loads in flight is the fast path's.
+__device__ __forceinline__ unsigned long long walk_repoll(const unsigned long long *p,
+                                                          unsigned long long tag, int lane) {
+  unsigned long long g = 0;
+  for (uint32_t spins = 0; spins < kWalkSpinLimit; ++spins) {
+    __builtin_amdgcn_s_sleep(4);
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(g)
+                 : "v"(p)
+                 : "memory");
+    if (__all((g >> 24) == tag || lane >= kWalkLanes)) break;
+  }
+  return g;  // the caller checks the tags once more: a mismatch now means the bound was hit
+}
+
+template <int SRC, int DEPTH>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const EncodeArgs a,
+                                                                       const WalkBatch wb) {
+  // one LDS object: the waves' 3 KiB store-staging slices, then the workgroup's ticket
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock * 3 * kStripPx + 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t *wg_ticket = stage + kWavesPerBlock * 3 * kStripPx;
+  if (threadIdx.x == 0)
+    *wg_ticket = __hip_atomic_fetch_add(&a.walk->ticket, 1u, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned long long serial = a.walk->serial;  // written by the previous launch
+  const int unit =
+      __builtin_amdgcn_readfirstlane((int)(*wg_ticket * (uint32_t)kWavesPerBlock) + wave);
+  if (unit < a.walk_units) {
+    const int f = unit / a.nstrips;
+    const int strip = unit - f * a.nstrips;
+    EncodeFrame fr;
+    fr.src = wb.src[f];
+    fr.sat = wb.sat[f];
+    fr.ws = 0;
+    fr.y = fr.src;
+    fr.u = wb.u[f];
+    fr.v = wb.v[f];
+    const int x0 = strip * kStripPx + lane * kLanePx;
+    const bool pub = strip + 1 < a.nstrips;
+    bool need = strip > 0;
+    const unsigned long long tag = serial & kWalkTagMask;
+    const int nb = a.walk_nbatches;
+    // my granules; the left neighbour's are one unit earlier (strip 0 polls its own: ignored)
+    unsigned long long *out =
+        a.walk_chain + (size_t)unit * nb * kWalkLanes + min(lane, kWalkLanes - 1);
+    const unsigned long long *in = need ? out - (size_t)nb * kWalkLanes : out;
+    const uint32_t mine =
+        (uint32_t)reinterpret_cast<uintptr_t>(stage) + wave * 3 * kStripPx * 4;
+    const int row_dwords = a.width * 3;
+    const int base = strip * kStripPx * 3;
+    const int y_last = a.height - 1;
+
+    uint32_t acc[12];  // the table row above, for this lane's 4 pixels (0 above the frame)
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 0;
+
+    auto walk_batch = [&](const RowBatch<SRC> &raw, unsigned long long g, int t) {
+      const int y = t * kRowUnroll;
+      // --- the strip's own sums of the 8 rows: lane totals, wave scans (kept), row totals
+      uint32_t inc_rg[kRowUnroll], inc_b[kRowUnroll];
+      uint32_t tot = 0;  // lane 3r + c: this strip's sum of row y + r, channel c
+#pragma unroll
+      for (int r = 0; r < kRowUnroll; ++r) {
+        uint32_t v[4];
+        batch_pixels<SRC>(a, raw, r, v);
+        uint32_t rb = 0, gg = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          rb += v[k] & 0x00ff00ffu;
+          gg += v[k] & 0x0000ff00u;
+        }
+        inc_rg[r] = wave_scan_incl((rb & 0xffffu) | (gg << 8));
+        inc_b[r] = wave_scan_incl(rb >> 16);
+        const uint32_t s_rg = (uint32_t)__builtin_amdgcn_readlane((int)inc_rg[r], 63);
+        const uint32_t s_b = (uint32_t)__builtin_amdgcn_readlane((int)inc_b[r], 63);
+        walk_writelane(tot, s_rg & 0xffffu, 3 * r);
+        walk_writelane(tot, s_rg >> 16, 3 * r + 1);
+        walk_writelane(tot, s_b, 3 * r + 2);
+      }
+      // --- hand-off: running row prefixes in from the left, out to the right
+      uint32_t lin = 0;
+      if (need) {
+        if (!__all((g >> 24) == tag || lane >= kWalkLanes)) {
+          g = walk_repoll(in + (size_t)t * kWalkLanes, tag, lane);
+          if (!__all((g >> 24) == tag || lane >= kWalkLanes)) {  // gave up: say so, stop waiting
+            if (lane == 0)
+              __hip_atomic_store(a.walk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            need = false;
+          }
+        }
+        lin = (uint32_t)g & 0xffffffu;
+      }
+      if (pub && lane < kWalkLanes)
+        walk_store_granule(out + (size_t)t * kWalkLanes,
+                           (tag << 24) | (unsigned long long)((lin + tot) & 0xffffffu));
+      // --- the table rows (sat_write_kernel's row step with the scans already done)
+#pragma unroll
+      for (int r = 0; r < kRowUnroll; ++r) {
+        if (y + r > y_last) break;
+        uint32_t c[12];
+        {
+          uint32_t v[4];
+          batch_pixels<SRC>(a, raw, r, v);
+          unpack_px4(make_uint4(v[0], v[1], v[2], v[3]), c);
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          c[3 * k + 0] += c[3 * k - 3];
+          c[3 * k + 1] += c[3 * k - 2];
+          c[3 * k + 2] += c[3 * k - 1];
+        }
+        const uint32_t base_r =
+            (inc_rg[r] & 0xffffu) - c[9] + (uint32_t)__builtin_amdgcn_readlane((int)lin, 3 * r);
+        const uint32_t base_g =
+            (inc_rg[r] >> 16) - c[10] + (uint32_t)__builtin_amdgcn_readlane((int)lin, 3 * r + 1);
+        const uint32_t base_b =
+            inc_b[r] - c[11] + (uint32_t)__builtin_amdgcn_readlane((int)lin, 3 * r + 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[3 * k + 0] += c[3 * k + 0] + base_r;
+          acc[3 * k + 1] += c[3 * k + 1] + base_g;
+          acc[3 * k + 2] += c[3 * k + 2] + base_b;
+        }
+        uint32_t *row = fr.sat + (size_t)(y + r) * a.width * 3;
+        lds_write_b128(mine + lane * 48, u32x4{acc[0], acc[1], acc[2], acc[3]});
+        lds_write_b128(mine + lane * 48 + 16, u32x4{acc[4], acc[5], acc[6], acc[7]});
+        lds_write_b128(mine + lane * 48 + 32, u32x4{acc[8], acc[9], acc[10], acc[11]});
+        u32x4 q[3];
+        lds_read3_b128(mine + lane * 16, q[0], q[1], q[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int off = k * 256 + lane * 4;
+          if (base + off < row_dwords)  // width % 4 == 0 -> whole 16 B in range
+            global_store_b128_uncounted_nt(row + base + off, q[k]);
+        }
+      }
+    };
+
+    // DEPTH batches of 8 rows rotate through static buffers, DEPTH - 1 of them in flight.  The
+    // poll of batch t is issued BEFORE the pixel loads of batch t + DEPTH - 1, so waiting for
+    // it leaves those in flight; every load is unconditional (rows clamped to the last row).
+    RowBatch<SRC> buf[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+      reduce_load_batch<SRC>(a, fr, buf[d], d * kRowUnroll, x0, y_last);
+    for (int t0 = 0; t0 < nb; t0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int t = t0 + d;
+        const unsigned long long g = __hip_atomic_load(
+            in + (size_t)min(t, nb - 1) * kWalkLanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reduce_load_batch<SRC>(a, fr, buf[(d + DEPTH - 1) % DEPTH], (t + DEPTH - 1) * kRowUnroll,
+                               x0, y_last);
+        if (t < nb) walk_batch(buf[d], g, t);
+      }
+    }
+  }
+  // retire: the last wave of the launch re-arms the state for the next one
+  if (lane == 0) {
+    const uint32_t waves = gridDim.x * kWavesPerBlock;
+    const uint32_t before = __hip_atomic_fetch_add(&a.walk->done, 1u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    if (before == waves - 1) {
+      unsigned long long next = serial + 1;
+      if ((next & kWalkTagMask) == 0) ++next;
+      __hip_atomic_store(&a.walk->serial, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.walk->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.walk->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false, int frames = 1) {
   f360::SatEncodePlan &p = ctx->enc;
   // band height: the largest of 64 / 32 / 16 rows that still yields enough tiles (one wave
@@ -790,9 +1027,15 @@ int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false, int f
     sb_bands = (nb + 31) / 32;
     if (sb_bands < 2) sb_bands = 2;
   }
-  if (p.width == width && p.height == height && p.band_rows == band_rows &&
-      p.sb_bands == sb_bands && p.ws.p && p.frames >= frames)
+  // The scratch is carved for the layout with the most super-bands (one band each), so callers
+  // that alternate planar and RGB0 sources on one context (different sb_bands at <= 4K) only
+  // change two numbers: no re-carve, no synchronisation.
+  if (p.width == width && p.height == height && p.band_rows == band_rows && p.ws.p &&
+      p.frames >= frames) {
+    p.sb_bands = sb_bands;
+    p.nsb = (p.nbands + sb_bands - 1) / sb_bands;
     return F360_OK;
+  }
   frames = std::max(frames, p.width == width && p.height == height ? p.frames : 1);
   // A geometry change re-carves the scratch; wait for work that may use it.
   if (p.ws.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -806,7 +1049,7 @@ int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false, int f
   p.wp3 = p.nstrips * kStripPx * 3;
   auto align = [](size_t n) { return (n + 63) & ~(size_t)63; };
   const size_t n_lp = align((size_t)p.nbands * p.wp3);
-  const size_t n_sb = align((size_t)p.nsb * p.wp3);
+  const size_t n_sb = align((size_t)p.nbands * p.wp3);  // room for sb_bands = 1
   const size_t n_row = align((size_t)p.nstrips * height * 3);
   const size_t n_tile = align((size_t)p.nstrips * p.nbands * 3);
   const size_t total = n_lp + 2 * n_sb + 2 * n_row + 2 * n_tile;
@@ -1010,6 +1253,108 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
 
 }  // namespace f360
 
+namespace {
+
+// Whether a batched call of `count` frames takes the read-once encoder ("sat.walk").
+bool walk_wanted(const f360_ctx *ctx, int count, int width) {
+  if (ctx->opt_walk == 0 || width > f360::kMaxDim) return false;
+  if (ctx->opt_walk == 1) return true;
+  const long strips = (width + kStripPx - 1) / kStripPx;
+  return (long)count * strips >= ctx->opt_walk_units;
+}
+
+// f360_sat_encode_batch / _yuv420p_batch on the read-once encoder: launches of up to kWalkFrames
+// frames.  The caller has checked the arguments and that every buffer allows 16-byte accesses.
+int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8_t *const *srcs,
+                    const f360::YuvPlanes *yuvs, int width, int height, int linesize,
+                    bool prof) {
+  f360::SatEncodePlan &p = ctx->enc;
+  const int nstrips = (width + kStripPx - 1) / kStripPx;
+  const int nb = (height + kRowUnroll - 1) / kRowUnroll;
+  const int per_launch = std::min(count, kWalkFrames);
+  // state words: zero ticket / done, serial 1; the launches advance them
+  if (!p.walk_state.p) {
+    int st = p.walk_state.reserve(64);
+    if (st != F360_OK) return st;
+    const WalkState init{0u, 0u, 1ull};
+    F360_HIP_TRY(hipMemsetAsync(p.walk_state.p, 0, 64, ctx->stream));
+    F360_HIP_TRY(hipMemcpyAsync(p.walk_state.p, &init, sizeof(init), hipMemcpyHostToDevice,
+                                ctx->stream));
+    F360_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `init` is a stack object
+  }
+  if (!p.walk_err_host) {
+    void *h = nullptr, *d = nullptr;
+    F360_HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+    *static_cast<uint32_t *>(h) = 0;
+    F360_HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+    p.walk_err_host = static_cast<uint32_t *>(h);
+    p.walk_err_dev = static_cast<uint32_t *>(d);
+  }
+  // granules: zeroed when (re)allocated -- a tag is never 0 -- and never again
+  const size_t chain_bytes = (size_t)per_launch * nstrips * nb * kWalkLanes * 8;
+  if (chain_bytes > p.walk_chain.bytes) {
+    if (p.walk_chain.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int st = p.walk_chain.reserve(chain_bytes);
+    if (st != F360_OK) return st;
+    F360_HIP_TRY(hipMemsetAsync(p.walk_chain.p, 0, p.walk_chain.bytes, ctx->stream));
+  }
+
+  EncodeArgs a{};
+  a.width = width;
+  a.height = height;
+  a.linesize = linesize;
+  a.bpp = 4;
+  a.nstrips = nstrips;
+  a.ablate = ctx->opt_ablate;
+  a.yuv = yuvs ? yuvs[0] : f360::YuvPlanes{nullptr, nullptr, nullptr, 0, 0, 0};
+  if (yuvs)
+    f360::build_yuv2rgb_consts(a.k);
+  else
+    a.k = f360::YuvConsts{};
+  a.walk_nbatches = nb;
+  a.walk = p.walk_state.as<WalkState>();
+  a.walk_chain = p.walk_chain.as<unsigned long long>();
+  a.walk_err = p.walk_err_dev;
+  const int yuv_src = !yuvs ? 0 : ctx->opt_yuv_model == 1 ? kSrcYuvSwsX86 : kSrcYuvSwsC;
+  const int depth = ctx->opt_walk_depth;
+
+  for (int k0 = 0; k0 < count; k0 += per_launch) {
+    const int n = std::min(count - k0, per_launch);
+    WalkBatch wb;
+    for (int k = 0; k < kWalkFrames; ++k) {
+      const int q = k0 + (k < n ? k : 0);
+      wb.src[k] = yuvs ? yuvs[q].y : srcs[q];
+      wb.sat[k] = sats[q];
+      wb.u[k] = yuvs ? yuvs[q].u : nullptr;
+      wb.v[k] = yuvs ? yuvs[q].v : nullptr;
+    }
+    a.walk_units = n * nstrips;
+    const dim3 grid((a.walk_units + kWavesPerBlock - 1) / kWavesPerBlock);
+    const dim3 block(64 * kWavesPerBlock);
+    f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
+#define F360_WALK_LAUNCH(SRC)                                                                   \
+  do {                                                                                          \
+    if (depth == 2)                                                                             \
+      hipLaunchKernelGGL((sat_walk_kernel<SRC, 2>), grid, block, 0, ctx->stream, a, wb);        \
+    else if (depth == 3)                                                                        \
+      hipLaunchKernelGGL((sat_walk_kernel<SRC, 3>), grid, block, 0, ctx->stream, a, wb);        \
+    else                                                                                        \
+      hipLaunchKernelGGL((sat_walk_kernel<SRC, 4>), grid, block, 0, ctx->stream, a, wb);        \
+  } while (0)
+    if (yuv_src == kSrcYuvSwsX86)
+      F360_WALK_LAUNCH(kSrcYuvSwsX86);
+    else if (yuv_src == kSrcYuvSwsC)
+      F360_WALK_LAUNCH(kSrcYuvSwsC);
+    else
+      F360_WALK_LAUNCH(kSrcRgb0);
+#undef F360_WALK_LAUNCH
+  }
+  F360_HIP_TRY(hipGetLastError());
+  return F360_OK;
+}
+
+}  // namespace
+
 extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev,
                                int width, int height, int linesize) {
   F360_REQUIRE(sat_dev, "f360_sat_encode: null buffer");
@@ -1034,6 +1379,19 @@ extern "C" int f360_sat_encode_batch(f360_ctx *ctx, int count, uint32_t *const *
       (size_t)f360_sat_encode_batch_max());
   F360_REQUIRE(ctx, "f360_sat_encode_batch: null context");
   const int prof = f360::take_profile_slot(ctx) ? 1 : 0;  // one slot for the whole call
+  // enough frames to fill the device with strip owners: the read-once encoder (sat_walk_kernel)
+  if (walk_wanted(ctx, count, width) && linesize / width == 4 && width % 4 == 0 &&
+      linesize % 16 == 0 && (size_t)width * height * 3 < ((size_t)1 << 31)) {
+    bool ok = true;
+    for (int k = 0; k < count && ok; ++k)
+      ok = sat_dev[k] && src_dev[k] && ((uintptr_t)src_dev[k] % 16) == 0 &&
+           ((uintptr_t)sat_dev[k] % 16) == 0;
+    if (ok) {
+      F360_BIND_DEVICE(ctx);
+      return sat_encode_walk(ctx, count, sat_dev, src_dev, nullptr, width, height, linesize,
+                             prof != 0);
+    }
+  }
   for (int k = 0; k < count; k += per_launch) {
     const int n = std::min(count - k, per_launch);
     const int st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr,

@@ -14,7 +14,12 @@ bump that re-serialises one of their inner loops would still pass every parity t
     no longer waits with a counted vmcnt at all;
   * any kernel contains v_ashr_pk_u8_i32 (hipcc 7.2 packs bytes wrongly around it).
 
-    python scripts/check_isa.py [path/to/libf360.so]        (exit 0 = all rules hold)
+The byte-packing rule and the sc1 bits of the strip walker's hand-off guard RESULTS and always
+fail; the others guard speed: they are printed as warnings (so a toolchain change cannot take the
+correctness tests down with the build) and fail only with --strict, which the CPU-tier test
+tests/test_isa_guard.py passes.
+
+    python scripts/check_isa.py [--strict] [path/to/libf360.so]      (exit 0 = rules hold)
 """
 import os
 import re
@@ -24,7 +29,19 @@ import sys
 import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def find_objdump():
+    """llvm-objdump of the ROCm toolchain: $ROCM_PATH, the default prefix, then PATH."""
+    for root in (os.environ.get("ROCM_PATH"), os.environ.get("ROCM_HOME"), "/opt/rocm"):
+        if root:
+            cand = os.path.join(root, "lib", "llvm", "bin", "llvm-objdump")
+            if os.path.exists(cand):
+                return cand
+    return shutil.which("llvm-objdump")
+
+
+OBJDUMP = find_objdump()
 
 
 def code_objects(lib):
@@ -68,9 +85,17 @@ def loops(ins):
 
 
 def main():
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "foveated-360-video_amd", "lib", "libf360.so")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    strict = "--strict" in sys.argv[1:]
+    lib = args[0] if args else os.path.join(REPO, "foveated-360-video_amd", "lib", "libf360.so")
+    if not OBJDUMP:
+        print("check_isa: skipped (no llvm-objdump under $ROCM_PATH, /opt/rocm or on PATH)")
+        return 0
     tmp, objs = code_objects(lib)
-    problems, seen = [], set()
+    # `errors` guard results (a known miscompile); `perf` guards speed only: a ROCm bump or a
+    # harmless scheduling change must not fail the build and with it every correctness test, so
+    # build() prints them as warnings and only --strict (tests/test_isa_guard.py) fails on them
+    errors, perf, seen = [], [], set()
     try:
         for obj in objs:
             for name, ins in functions(obj).items():
@@ -81,13 +106,13 @@ def main():
                     seen.add("writer")
                     stores = [t for t in texts if t.startswith("global_store_dwordx4")]
                     if any(" nt" not in t for t in stores):
-                        problems.append(f"{name}: a table store lost its nt bit")
+                        perf.append(f"{name}: a table store lost its nt bit")
                     for lp in loops(ins):
                         lt = [t for _, t, _ in lp]
                         if any(t.startswith("global_store_dwordx") for t in lt) and \
                                 any(t.startswith("s_waitcnt vmcnt(0)") for t in lt):
-                            problems.append(f"{name}: s_waitcnt vmcnt(0) inside a storing loop "
-                                            f"({len(lt)} instructions)")
+                            perf.append(f"{name}: s_waitcnt vmcnt(0) inside a storing loop "
+                                        f"({len(lt)} instructions)")
                 if re.search(r"sat_reduce_kernelILi[123]EE", name):
                     seen.add("reducer")
                     # the steady-state loop: a batch of >= 8 row loads, waits that count the
@@ -98,35 +123,69 @@ def main():
                               any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in lt) and
                               not any(t.startswith("s_waitcnt vmcnt(0)") for t in lt)]
                     if not steady:
-                        problems.append(f"{name}: no row-batch loop with counted waits only")
+                        perf.append(f"{name}: no row-batch loop with counted waits only")
+                # the read-once batched encoder (RGB0 and planar sources): no scratch memory, nt
+                # table stores, write-through granule stores, an sc1 poll, and a steady-state
+                # loop whose only drain is the slow path of a hand-off wait (it follows its own
+                # sc1 load directly)
+                if re.search(r"sat_walk_kernelILi[123]ELi[234]EE", name):
+                    seen.add("walker")
+                    if any(t.startswith(("scratch_", "s_swappc")) for t in texts):
+                        perf.append(f"{name}: scratch memory or a call in the strip walker")
+                    if any(t.startswith("global_store_dwordx4") and " nt" not in t for t in texts):
+                        perf.append(f"{name}: a table store lost its nt bit")
+                    gran = [t for t in texts if t.startswith("global_store_dwordx2")]
+                    if not gran or any(" sc1" not in t for t in gran):
+                        errors.append(f"{name}: hand-off granule stores must be sc1 (write-through)")
+                    polls = [t for t in texts if t.startswith("global_load_dwordx2")]
+                    if len([t for t in polls if " sc1" in t]) < 2:
+                        errors.append(f"{name}: hand-off polls must be sc1 loads")
+                    # between the first and the last table store the only full drains allowed
+                    # are the slow path's (each directly behind its own sc1 poll load)
+                    st = [i for i, t in enumerate(texts) if t.startswith("global_store_dwordx4")]
+                    if st:
+                        body = texts[st[0]:st[-1] + 1]
+                        bad = [i for i, t in enumerate(body) if t.startswith("s_waitcnt vmcnt(0)")
+                               and not (i > 0 and body[i - 1].startswith("global_load_dwordx2")
+                                        and " sc1" in body[i - 1])]
+                        if bad:
+                            perf.append(f"{name}: {len(bad)} s_waitcnt vmcnt(0) on the fast path "
+                                        f"of the row loop")
+                        if not any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in body):
+                            perf.append(f"{name}: the row loop has no counted vmcnt wait")
                 # hipcc 7.2 miscompiles byte packing around this instruction (its upper half is
                 # not zero on gfx950 but later ORs assume so): both times it appeared, the parity
                 # tests failed; the kernels are written so that it is not selected
                 if any(t.startswith("v_ashr_pk_u8_i32") for t in texts):
-                    problems.append(f"{name}: v_ashr_pk_u8_i32 selected (known-bad byte packing)")
-                if "sample_rect_stream_kernel" in name:
-                    seen.add("streamer")
+                    errors.append(f"{name}: v_ashr_pk_u8_i32 selected (known-bad byte packing)")
+                if "sample_rect_stream_kernel" in name or "sample_rect_stream_batch_kernel" in name:
+                    seen.add("batch streamer" if "batch" in name else "streamer")
                     row_loops = [[t for _, t, _ in lp] for lp in loops(ins)
                                  if any(t.startswith("global_load_lds_dwordx4") for _, t, _ in lp)]
                     if not row_loops:
-                        problems.append(f"{name}: no loop with LDS-direct loads")
+                        perf.append(f"{name}: no loop with LDS-direct loads")
                     for lt in row_loops:
                         if any(t.startswith("s_waitcnt vmcnt(0)") for t in lt):
-                            problems.append(f"{name}: s_waitcnt vmcnt(0) inside the row loop")
+                            perf.append(f"{name}: s_waitcnt vmcnt(0) inside the row loop")
                         if not any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in lt):
-                            problems.append(f"{name}: the row loop has no counted vmcnt wait")
+                            perf.append(f"{name}: the row loop has no counted vmcnt wait")
                     if not any(t.startswith("global_store_short") and " nt" in t for t in texts):
-                        problems.append(f"{name}: pixel stores lost their nt bit")
+                        perf.append(f"{name}: pixel stores lost their nt bit")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for k in ("writer", "reducer", "streamer"):
+    for k in ("writer", "reducer", "walker", "streamer", "batch streamer"):
         if k not in seen:
-            problems.append(f"no {k} kernel found in {lib}")
-    if problems:
-        print("check_isa: FAILED\n  " + "\n  ".join(problems))
+            perf.append(f"no {k} kernel found in {lib}")
+    for p in perf:
+        print(("check_isa: FAILED (perf rule): " if strict else "check_isa: warning (perf rule): ") + p)
+    if errors:
+        print("check_isa: FAILED\n  " + "\n  ".join(errors))
         return 1
-    print(f"check_isa: ok ({len(objs)} gfx950 code objects; writer, reducer and streamer loops keep "
-          f"their counted waits, LDS-direct loads and nt stores)")
+    if strict and perf:
+        return 1
+    print(f"check_isa: ok ({len(objs)} gfx950 code objects; "
+          + ("writer, reducer, strip-walker and streamer loops keep their counted waits, "
+             "LDS-direct loads, nt and sc1 bits" if not perf else f"{len(perf)} perf warnings") + ")")
     return 0
 
 

@@ -1,0 +1,146 @@
+"""GPU tier: the read-once batched SAT encoder (sat_walk_kernel, option "sat.walk") against the
+CPU oracle.  One wave walks a 256-pixel strip of one frame from top to bottom and takes the row
+prefixes of the strips to its left through tagged 8-byte hand-off granules; the table must be
+the oracle's bit for bit -- any stale, torn or early-read granule shows up as a wrong sum in
+every row below it.  The cases force the kernel on geometries the automatic choice would give to
+the three-kernel encoder (few strips, one strip, ragged edges, heights that are not a multiple
+of the 8-row batch) and run it under uneven load (many frames of different cost in flight,
+a second stream hammering memory, re-used and re-carved hand-off buffers)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _encode_batch_and_check(f360, ctx, oracle, w, h, n, pad=0, seed=900, frames=None):
+    ls = 4 * w + pad
+    if frames is None:
+        frames = [oracle.lcg_frame(w, h, seed + k, bpp=4, linesize=ls) for k in range(n)]
+    srcs = [ctx.upload(np.ascontiguousarray(f).reshape(-1)) for f in frames]
+    sats = [ctx.malloc(w * h * 12) for _ in range(n)]
+    for s in sats:
+        s.fill(0xEE)
+    f360.SATEncoder(ctx).EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, ls)
+    bad = []
+    for k in range(n):
+        got = sats[k].copy_to_host(np.uint32, (h, w, 3))
+        if not np.array_equal(got, oracle.sat_encode(frames[k], w, h, ls)):
+            bad.append(k)
+    for b in srcs + sats:
+        b.free()
+    return bad
+
+
+@pytest.fixture()
+def walk_ctx(gpu_ctx):
+    gpu_ctx.set_option("sat.walk", 1)
+    yield gpu_ctx
+    gpu_ctx.set_option("sat.walk", -1)
+    gpu_ctx.set_option("sat.walk_depth", 2)
+
+
+@pytest.mark.parametrize("w,h,n,pad", [
+    (1336, 203, 5, 0),      # ragged last strip, height not a multiple of 8
+    (1920, 1080, 3, 0),     # the reference's operating point
+    (256, 128, 19, 16),     # one strip per frame: no hand-off at all; padded rows
+    (260, 9, 2, 0),         # two strips, the second 4 pixels wide; two batches, the second 1 row
+    (4, 1, 1, 0), (8, 7, 3, 0), (512, 8, 4, 0), (516, 17, 70, 0),   # 70 frames: two launches
+    (3840, 64, 2, 0),       # 15 strips, 8 batches
+    (1024, 512, 40, 0),     # 160 units in flight
+])
+def test_walk_encode_matches_oracle(f360, walk_ctx, oracle, w, h, n, pad):
+    assert _encode_batch_and_check(f360, walk_ctx, oracle, w, h, n, pad) == []
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_walk_depths(f360, walk_ctx, oracle, depth):
+    walk_ctx.set_option("sat.walk_depth", depth)
+    for w, h, n in [(1336, 203, 3), (2048, 50, 4), (772, 23, 2)]:
+        assert _encode_batch_and_check(f360, walk_ctx, oracle, w, h, n) == [], (w, h, n)
+
+
+def test_walk_repeated_and_recarved(f360, walk_ctx, oracle):
+    """The hand-off granules are never cleared between launches: the launch serial in their tag
+    tells this launch's from older ones.  Same geometry many times, then another geometry whose
+    strips land on the old granules, then the first again; a single-frame encode (the
+    three-kernel path, which shares nothing with it) in between."""
+    for rep in range(6):
+        assert _encode_batch_and_check(f360, walk_ctx, oracle, 1024, 64, 6, seed=10 * rep) == []
+    assert _encode_batch_and_check(f360, walk_ctx, oracle, 520, 130, 3) == []
+    assert _encode_batch_and_check(f360, walk_ctx, oracle, 2048, 40, 9) == []   # larger: re-carve
+    frame = oracle.lcg_frame(640, 48, 5)
+    src, sat = walk_ctx.upload(frame), walk_ctx.malloc(640 * 48 * 12)
+    f360.SATEncoder(walk_ctx).EncodeFrameGPU(sat.ptr, src.ptr, 640, 48, 4 * 640)
+    assert np.array_equal(sat.copy_to_host(np.uint32, (48, 640, 3)),
+                          oracle.sat_encode(frame, 640, 48, 4 * 640))
+    src.free()
+    sat.free()
+    assert _encode_batch_and_check(f360, walk_ctx, oracle, 1024, 64, 6, seed=77) == []
+
+
+def test_walk_special_frames(f360, walk_ctx, oracle):
+    """All-255 (largest row prefixes: the 24-bit payload of a granule), all-zero and a frame
+    whose 4th byte is garbage."""
+    w, h = 4096, 96
+    frames = [np.full((h, 4 * w), 255, dtype=np.uint8), np.zeros((h, 4 * w), dtype=np.uint8),
+              oracle.lcg_frame(w, h, 3)]
+    assert _encode_batch_and_check(f360, walk_ctx, oracle, w, h, 3, frames=frames) == []
+
+
+def test_walk_under_uneven_load(f360, oracle):
+    """A second context on its own stream streams through memory while the strip owners hand
+    their prefixes along: hand-offs must not depend on timing or placement."""
+    with f360.Context(0) as a, f360.Context(0) as b:
+        a.set_option("sat.walk", 1)
+        w, h, n = 2304, 256, 24
+        frames = [oracle.lcg_frame(w, h, 300 + k) for k in range(n)]
+        srcs = [a.upload(f) for f in frames]
+        sats = [a.malloc(w * h * 12) for _ in range(n)]
+        big_src = b.upload(oracle.lcg_frame(3840, 1920, 1))
+        big_sat = b.malloc(3840 * 1920 * 12)
+        enc_a, enc_b = f360.SATEncoder(a), f360.SATEncoder(b)
+        for rep in range(4):
+            for s in sats:
+                s.fill(rep)
+            for _ in range(6):
+                enc_b.EncodeFrameGPU(big_sat.ptr, big_src.ptr, 3840, 1920, 4 * 3840)
+            enc_a.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, 4 * w)
+            for _ in range(6):
+                enc_b.EncodeFrameGPU(big_sat.ptr, big_src.ptr, 3840, 1920, 4 * 3840)
+            for k in range(n):
+                assert np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)),
+                                      oracle.sat_encode(frames[k], w, h, 4 * w)), (rep, k)
+            b.finish()
+        for x in srcs + sats:
+            x.free()
+        big_src.free()
+        big_sat.free()
+
+
+def test_walk_equals_three_kernel_encoder_at_8k(f360, gpu_ctx, oracle, golden_digests=None):
+    """Full size: three 8K frames (a seeded one, the golden one, the all-255 frame whose sums
+    wrap mod 2^32) through both batched encoders; digests equal, and the golden frame's is the
+    committed one."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "digests.json")) as f:
+        dig = json.load(f)
+    w, h = 7680, 3840
+    ent = dig["cases"][f"{w}x{h}"]
+    frames = [oracle.lcg_frame(w, h, 7), oracle.lcg_frame(w, h, dig["seed"]),
+              np.full((h, 4 * w), 255, dtype=np.uint8)]
+    srcs = [gpu_ctx.upload(f) for f in frames]
+    sats = [gpu_ctx.malloc(w * h * 12) for _ in frames]
+    enc = f360.SATEncoder(gpu_ctx)
+    out = {}
+    for walk in (0, 1):
+        gpu_ctx.set_option("sat.walk", walk)
+        for s in sats:
+            s.fill(0x5A)
+        enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, 4 * w)
+        out[walk] = [f"{oracle.fnv1a64(s.copy_to_host(np.uint32, (h, w, 3))):016x}" for s in sats]
+    gpu_ctx.set_option("sat.walk", -1)
+    for b in srcs + sats:
+        b.free()
+    assert out[0] == out[1]
+    assert out[1][1] == ent["sat"] and out[1][2] == ent["sat_white"]
