@@ -54,15 +54,25 @@ def algorithmic_bytes(w, h, rw, rh):
     return enc, smp
 
 
-def cpu_baseline(w, h, rw, rh, per_thread=6):
+CPU_SHARE_PER_GPU = 16  # this pool gives a one-GPU box 16 CPUs (more runnable threads are killed)
+
+
+def cpu_baseline(w, h, rw, rh, passes=3):
     """The oracle's SAT encode + sample (kind "port") on the host cores, COMPUTE ONLY: every
-    thread synthesises its frames first, all threads meet at a barrier, and the clock runs from
-    there to the last thread's end.  Bounded sample: per_thread frames on each of <= 16 threads."""
+    thread synthesises its two frames first, all threads meet at a barrier, and the clock runs
+    from there to the last thread's end.  Bounded sample: `passes` passes over 2 frames on each
+    thread (0.7 GB per thread: two frames, the table, the reduced frame and the grid).  Threads =
+    the cores this process may run on, capped at the GPU box's CPU share (stated in the line)."""
     import threading
     import numpy as np
     import oracle_binding as ob
     ob.lib()
-    cores = max(1, min(16, os.cpu_count() or 1))
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    cores = max(1, min(visible, CPU_SHARE_PER_GPU))
+    held = 2
     # one thread alone, two frames
     solo = np.stack([ob.lcg_frame(w, h, 1).reshape(h, 4 * w), ob.lcg_frame(w, h, 2).reshape(h, 4 * w)])
     _, t_solo = ob.pipeline_compute(solo, 0, w, h, rw, rh)
@@ -72,11 +82,13 @@ def cpu_baseline(w, h, rw, rh, per_thread=6):
     ends, busy = [0.0] * cores, [0.0] * cores
 
     def worker(i):
-        mine = np.empty((per_thread, h, 4 * w), dtype=np.uint8)
-        for k in range(per_thread):  # ctypes releases the GIL during the fill
+        mine = np.empty((held, h, 4 * w), dtype=np.uint8)
+        for k in range(held):  # ctypes releases the GIL during the fill
             mine[k] = ob.lcg_frame(w, h, 1000 + 100 * i + k).reshape(h, 4 * w)
         gate.wait()
-        _, busy[i] = ob.pipeline_compute(mine, i * per_thread, w, h, rw, rh)
+        for p in range(passes):
+            _, t = ob.pipeline_compute(mine, i * held * passes + p * held, w, h, rw, rh)
+            busy[i] += t
         ends[i] = time.perf_counter()
 
     threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
@@ -87,17 +99,22 @@ def cpu_baseline(w, h, rw, rh, per_thread=6):
     for t in threads:
         t.join()
     wall = max(ends) - t0
-    frames = per_thread * cores
+    frames = held * passes * cores
     return {
         "value": round(frames * w * h / 1e6 / wall, 1),
         "unit": "Mpixels/s",
         "cores": cores,
+        "cores_visible": visible,
+        "cores_cap": f"{CPU_SHARE_PER_GPU} = the CPU share of a one-GPU box on this pool",
         "kind": "port",
         "single_thread_value": round(single, 1),
-        "sample": (f"{frames} frames {w}x{h} ({per_thread} per thread x {cores} threads) synthesised "
-                   f"before the clock starts; oracle f360o_sat_encode + f360o_satdec_sample_rect, "
-                   f"compute-only wall {wall:.2f}s ({sum(busy):.1f} core-s); one thread alone: "
-                   f"{single:.1f} Mpixels/s"),
+        # the reference's own SATEncoder::EncodeFrameCPU (encode only,
+        # column-major loops, one thread, survey container) at 7680x3840; the port walks rows
+        "reference_cpu_indicative_mpix_s": 22 if (w, h) == (7680, 3840) else None,
+        "sample": (f"{frames} frame passes {w}x{h} ({passes} passes x {held} frames per thread x "
+                   f"{cores} threads), frames synthesised before the clock starts; oracle "
+                   f"f360o_sat_encode + f360o_satdec_sample_rect, compute-only wall {wall:.2f}s "
+                   f"({sum(busy):.1f} core-s); one thread alone: {single:.1f} Mpixels/s"),
     }
 
 
@@ -142,12 +159,14 @@ def main():
                          "blocks (BASELINE config 4: 64 -> 8 per GPU at N = 8); overrides --batch")
     ap.add_argument("--dry-run", action="store_true",
                     help="print the launch command and the per-rank frame ranges; no GPU call")
-    ap.add_argument("--frames-per-call", type=int, default=8,
+    ap.add_argument("--frames-per-call", type=int, default=64,
                     help="two-call path: N frames per EncodeFramesGPU / EncodeFramesYUV420PGPU call, then one "
-                         "SampleFramesRectGPU call for their N tables (the frames share launches: "
-                         "the encoder as many as stay cache-resident between its two reads -- one "
-                         "at 8K --, the sampler all N); 1 = EncodeFrameGPU + SampleFrameRectGPU "
-                         "per frame, the reference's own loop")
+                         "SampleFramesRectGPU call for their N tables.  With enough frames to fill the "
+                         "device (960 strips: 32 frames at 8K) the encode call takes the read-once "
+                         "encoder (one launch, sat_walk_kernel), below that the three-kernel one; the "
+                         "sampler shares launches of 16.  1 = EncodeFrameGPU + SampleFrameRectGPU "
+                         "per frame, the reference's own loop (also reported: "
+                         "value_reference_call_shape)")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (in-order streams) per GPU; frames go round-robin over them "
                          "(3 gives ~15%% more throughput; 1 keeps every kernel launch comparable with "
@@ -172,6 +191,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1 or args.batch < 1 or args.global_batch < 0:
         ap.error("--gpus and --batch must be >= 1, --global-batch >= 0")
+    if args.profile_every < 1 or args.frames_per_call < 1:
+        ap.error("--profile-every and --frames-per-call must be >= 1")
     if args.global_batch and args.global_batch < args.gpus:
         ap.error("--global-batch smaller than --gpus leaves ranks without a frame")
 
@@ -249,9 +270,10 @@ def main():
     for d in decs:
         d.InitializeGrid(rw, rh, w, h)
     # (several streams: frames go round-robin over the contexts one call pair at a time)
-    fpc = 1 if (args.fused or nstreams > 1) else max(1, min(args.frames_per_call, B))
+    fpc = 1 if args.fused else max(1, min(args.frames_per_call, B))
+    # one set of tables per context: a call pair's tables live until its sample call has run
     sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev)
-            for _ in range(max(len(ctxs), fpc))]
+            for _ in range(len(ctxs) * fpc)]
     reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
     gazes = [lissajous(g) for g in mine]
     if yuv:
@@ -266,20 +288,31 @@ def main():
     calls = [0]
 
     def step_batched(profile):
-        # frames [g, g + n) in one encode call and one sample call; every profile_every-th
-        # call pair is the sampled one (counted across steps)
+        # frames [g, g + n) in one encode call and one sample call; --profile-every counts
+        # frames, so with n >= that every call pair is a sampled one (event pairs around
+        # launches that cover n frames cost nothing measurable).  Call pairs go round-robin
+        # over the contexts (--streams); a sampled one runs alone on the GPU.
         for g in range(0, B, fpc):
             n = min(fpc, B - g)
+            s = calls[0] % nstreams
             calls[0] += 1
-            sampled = profile and calls[0] % args.profile_every == 1
+            sampled = profile and (calls[0] - 1) % max(1, args.profile_every // fpc) == 0
             if sampled:
-                ctxs[0].profile_arm(2)
+                for o in range(nstreams):
+                    if o != s:
+                        streams[s].wait_stream(streams[o])
+                ctxs[s].profile_arm(2)
+            mine_sats = sat_ptr[s * fpc:s * fpc + n]
             if yuv:
-                encs[0].EncodeFramesYUV420PGPU(sat_ptr[:n], yuv_ptr[g:g + n], w, w // 2, w // 2, w, h)
+                encs[s].EncodeFramesYUV420PGPU(mine_sats, yuv_ptr[g:g + n], w, w // 2, w // 2, w, h)
             else:
-                encs[0].EncodeFramesGPU(sat_ptr[:n], frame_ptr[g:g + n], w, h, 4 * w)
-            decs[0].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n], (w, h),
+                encs[s].EncodeFramesGPU(mine_sats, frame_ptr[g:g + n], w, h, 4 * w)
+            decs[s].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, mine_sats, (w, h),
                                         gazes[g:g + n])
+            if sampled:
+                for o in range(nstreams):
+                    if o != s:
+                        streams[o].wait_stream(streams[s])
 
     def step(profile):
         if fpc > 1:
@@ -336,8 +369,10 @@ def main():
     # the only collective of the run: RCCL max of the timing / sum of the pixels
     from importlib import import_module
     sharding = import_module("foveated-360-video_amd.sharding")
+    my_elapsed = elapsed
     elapsed, total_px = sharding.reduce_run(elapsed, float(args.steps) * B * w * h,
                                             device=dev if args.backend == "nccl" else None)
+    per_rank = sharding.gather_run(my_elapsed, B, device=dev if args.backend == "nccl" else None)
 
     # ---- per-kernel times of the sampled frames (HIP events on the launch stream) --------
     prof = {}
@@ -363,41 +398,50 @@ def main():
         enc_bytes -= (4 * w * h) - (w * h * 3) // 2  # the frame is 1.5 B/px in planes
 
     if rank == 0:
-        # dominant kernel: sat_write_kernel.  Its algorithmic bytes per launch: it is the
-        # kernel that produces the table, so it is charged the encode's compulsory traffic
-        # (4 B/px frame read -- 1.5 from planes -- + 12 B/px table write; DESIGN.md "Roofline
-        # accounting").  In fused mode it emits the distinct box corners instead of the table:
-        # frame read + 12 B per corner.
-        dom = "sat_write_kernel"
-        roof = None
+        # Per-kernel roofline entries.  Algorithmic bytes per frame (DESIGN "Roofline
+        # accounting"): the kernel that produces the table -- sat_walk_kernel (read-once
+        # encoder) or sat_write_kernel (three-kernel encoder) -- is charged the encode's
+        # compulsory traffic (4 B/px frame read -- 1.5 from planes -- + 12 B/px table write); the
+        # reducer and the carry kernel of the three-kernel encoder do no algorithmic work (their
+        # bytes are overhead); the sampler is charged the distinct corners + the reduced frame.
+        # In fused mode the writer emits the distinct box corners instead of the table.
         frame_bytes = (w * h * 3) // 2 if yuv else 4 * w * h
-        if dom in kernels:
-            avg_s = kernels[dom]["avg_us"] * 1e-6
-            dom_bytes = frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes
-            fpl = kernels[dom].get("frames_per_launch", 1)  # frames one launch of it covers
-            dom_bytes = int(dom_bytes * fpl)
-            achieved = dom_bytes / avg_s / 1e9
-            # PMC traffic is a measurement of a particular build: profiles/pmc_traffic.json carries
-            # the hash of the kernel sources it was taken on and is ignored (null) for any other
-            traffic = None
-            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath) and not args.fused:
-                try:
-                    sys.path.insert(0, os.path.join(REPO, "scripts"))
-                    from pmc_traffic import csrc_hash
-                    with open(tpath) as f:
-                        doc = json.load(f)
-                    if doc.get("csrc_sha") == csrc_hash():
-                        traffic = doc.get(dom, {}).get(f"{w}x{h}" + (":yuv420p" if yuv else ""))
-                        if traffic is not None:
-                            traffic = int(traffic * fpl)
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": dom + (" (emit mode)" if args.fused else ""),
-                    "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
-                    "avg_launch_us": kernels[dom]["avg_us"]}
+        alg = {"sat_walk_kernel": enc_bytes,
+               "sat_write_kernel": frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes,
+               "sat_reduce_kernel": 0, "sat_carry_kernel": 0,
+               "sample_rect_kernel": smp_bytes}
+        # PMC traffic is a measurement of a particular build: profiles/pmc_traffic.json carries
+        # the hash of the kernel sources it was taken on and is ignored (null) for any other
+        pmc = {}
+        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and not args.fused:
+            try:
+                sys.path.insert(0, os.path.join(REPO, "scripts"))
+                from pmc_traffic import csrc_hash
+                with open(tpath) as f:
+                    doc = json.load(f)
+                if doc.get("csrc_sha") == csrc_hash():
+                    pmc = doc
+            except Exception:
+                pmc = {}
+        size_key = f"{w}x{h}" + (":yuv420p" if yuv else "")
+
+        def roof_of(name):
+            k = kernels[name]
+            fpl = k.get("frames_per_launch", 1)  # frames one launch of it covers
+            nbytes = int(alg[name] * fpl)
+            gbs = nbytes / (k["avg_us"] * 1e-6) / 1e9
+            traffic = pmc.get(name, {}).get(size_key) if isinstance(pmc.get(name), dict) else None
+            return {"bound": "hbm", "kernel": name + (" (emit mode)" if args.fused and name == "sat_write_kernel" else ""),
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": int(traffic * fpl) if traffic is not None else None,
+                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": k["avg_us"],
+                    "frames_per_launch": fpl}
+        roofline_kernels = {name: roof_of(name) for name in alg if name in kernels}
+        # the dominant kernel: the one that moves the table
+        dom = "sat_walk_kernel" if "sat_walk_kernel" in kernels else "sat_write_kernel"
+        roof = roofline_kernels.get(dom)
         # whole path: SURVEY 8(d)'s figure for the two calls; fused, the table and its re-read are
         # not algorithmic work any more: frame in + reduced frame out
         path_bytes = (frame_bytes + 4 * rw * rh) if args.fused else enc_bytes + smp_bytes
@@ -426,11 +470,46 @@ def main():
                        "source": args.source, "fused": bool(args.fused),
                        "frame": [w, h], "reduced": [rw, rh], "batch_per_gpu": B,
                        "global_batch": args.global_batch or None,
-                       "streams_per_gpu": nstreams, "frames_per_call": fpc, "parallelism": f"frames sharded x{world}"},
+                       "streams_per_gpu": nstreams, "frames_per_call": fpc,
+                       # which encoder the encode calls took: the read-once strip walker needs
+                       # enough frames per call to fill the device, below that (e.g. 8 frames per
+                       # rank with --global-batch 64 on 8 GPUs) the three-kernel encoder runs
+                       "encoder": ("fused (emit mode)" if args.fused else
+                                   "read-once (sat_walk_kernel)" if "sat_walk_kernel" in kernels
+                                   else "three kernels (reduce, carry, write)"),
+                       "parallelism": f"frames sharded x{world}"},
             "roofline": roof,
+            "roofline_kernels": roofline_kernels,
             "path_hbm_frac": round(path_bytes * (total_px / (w * h)) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "kernels": kernels,
         }
+        if world > 1:  # a straggler is visible: every rank's frames and ms per step
+            line["per_rank"] = [{"rank": r, "frames": n, "ms_per_step": round(1e3 * t / args.steps, 4)}
+                                for r, n, t in per_rank]
+        if world == 1 and not args.fused and fpc > 1 and not args.no_variants:
+            # The reference's own call shape on the same frames, outside the timed region: one
+            # EncodeFrameGPU + one SampleFrameRectGPU per frame (src/video_server.cc:300,336)
+            def per_frame_pair(k):
+                if yuv:
+                    encs[0].EncodeFrameYUV420PGPU(sat_ptr[0], *yuv_ptr[k], w, w // 2, w // 2, w, h)
+                else:
+                    encs[0].EncodeFrameGPU(sat_ptr[0], frame_ptr[k], w, h, 4 * w)
+                decs[0].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[0], (w, h),
+                                           gazes[k][0], gazes[k][1])
+            for k in range(B):
+                per_frame_pair(k)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                for k in range(B):
+                    per_frame_pair(k)
+            torch.cuda.synchronize(dev)
+            ref_value = 3 * B * w * h / 1e6 / (time.perf_counter() - t1)
+            line["value_reference_call_shape"] = round(ref_value, 1)
+            line["reference_call_shape"] = ("one EncodeFrameGPU + one SampleFrameRectGPU per frame "
+                                            "(src/video_server.cc:300,336), 3 steps after the timed "
+                                            "region; path_hbm_frac "
+                                            f"{path_bytes * ref_value * 1e6 / (w * h) / 1e9 / HBM_PEAK_GBS:.4f}")
         if world == 1 and not args.no_variants and not args.fused and not yuv:
             # Outside the timed region, for information: the same frames through the fused call
             # (same bytes out, no table) and from planar YUV 4:2:0; a few steps each.

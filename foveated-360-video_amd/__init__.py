@@ -143,6 +143,7 @@ _SIGNATURES = {
     "f360_ctx_profile_arm": (c_int, [c_void_p, c_int]),
     "f360_ctx_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "f360_ctx_profile_frames": (c_int, [c_void_p, c_int, POINTER(c_int)]),
+    "f360_debug_walk_stats": (c_int, [c_void_p, c_void_p, c_int]),
     "f360_ctx_profile_reset": (c_int, [c_void_p]),
     "f360_tables_satdec_grid_axis": (c_int, [c_void_p, c_int, c_int]),
     "f360_tables_is_grid_axis": (c_int, [c_void_p, c_int, c_int]),
@@ -273,6 +274,16 @@ class Context:
             if n.value:
                 out[lib().f360_kernel_name(k).decode()] = n.value
         return out
+
+    def debug_walk_stats(self, max_units: int = 4096):
+        """(units, 4) uint64 array {start, end, slow waits, polls} of the last read-once encoder
+        launch that ran with debug.ablate bit 8 (f360_debug_walk_stats)."""
+        import numpy as np
+        out = np.zeros((max_units, 4), dtype=np.uint64)
+        n = lib().f360_debug_walk_stats(self._h, out.ctypes.data_as(c_void_p), max_units)
+        if n < 0:
+            _check(n)
+        return out[:n]
 
     def malloc(self, nbytes: int) -> "DeviceBuffer":
         return DeviceBuffer(self, nbytes)

@@ -305,7 +305,7 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
       if (s.field == &f360_ctx::opt_walk)
         F360_REQUIRE(value >= -1 && value <= 1, "sat.walk must be -1 (automatic), 0 or 1: %d", value);
       if (s.field == &f360_ctx::opt_walk_depth)
-        F360_REQUIRE(value >= 2 && value <= 4, "sat.walk_depth must be 2, 3 or 4: %d", value);
+        F360_REQUIRE(value >= 2 && value <= 3, "sat.walk_depth must be 2 or 3: %d", value);
       if (s.field == &f360_ctx::opt_walk_units)
         F360_REQUIRE(value >= 1, "sat.walk_units must be >= 1: %d", value);
       if (s.field == &f360_ctx::opt_sample_variant)

@@ -162,6 +162,7 @@ struct EncodeArgs {
   struct WalkState *walk;
   unsigned long long *walk_chain;  // [unit][batch][24] {tag:40 | row prefix:24}
   uint32_t *walk_err;              // host-visible: a hand-off wait ran into its bound
+  unsigned long long *walk_stats;  // debug.ablate bit 8: per unit {start, end, slow polls, spins}
 };
 // (a kernel argument of its own: inside EncodeArgs the arrays keep the compiler from taking
 // that struct apart, it lands in scratch memory and the row loops wait on vmcnt(0))
@@ -826,9 +827,11 @@ __device__ __forceinline__ void walk_store_granule(unsigned long long *p, unsign
 // did not find this launch's tag in all 24 granules.  Self-contained asm loads with their own
 // full wait, so the compiler's count of the pixel loads in flight is the fast path's.
 __device__ __forceinline__ unsigned long long walk_repoll(const unsigned long long *p,
-                                                          unsigned long long tag, int lane) {
+                                                          unsigned long long tag, int lane,
+                                                          uint32_t &spun) {
   unsigned long long g = 0;
   for (uint32_t spins = 0; spins < kWalkSpinLimit; ++spins) {
+    ++spun;
     __builtin_amdgcn_s_sleep(4);
     asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(g)
@@ -837,6 +840,26 @@ __device__ __forceinline__ unsigned long long walk_repoll(const unsigned long lo
     if (__all((g >> 24) == tag || lane >= kWalkLanes)) break;
   }
   return g;  // the caller checks the tags once more: a mismatch now means the bound was hit
+}
+
+// A batch of the walker's pixel loads: read exactly once, by exactly one wave
+template <int SRC>
+__device__ __forceinline__ void walk_load_batch(const EncodeArgs &a, const EncodeFrame &fr,
+                                                RowBatch<SRC> &b, int y, int x0, int y_last) {
+#ifdef F360_WALK_NT_LOADS
+  if constexpr (SRC == kSrcRgb0) {
+    const int xc = min(x0, a.width - kLanePx);
+    const uint8_t *p = fr.src + (size_t)xc * 4;
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r) {
+      const u32x4 v = __builtin_nontemporal_load(
+          reinterpret_cast<const u32x4 *>(p + (size_t)min(y + r, y_last) * a.linesize));
+      b.raw[r] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return;
+  }
+#endif
+  reduce_load_batch<SRC>(a, fr, b, y, x0, y_last);
 }
 
 template <int SRC, int DEPTH>
@@ -866,7 +889,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const Enc
     fr.v = wb.v[f];
     const int x0 = strip * kStripPx + lane * kLanePx;
     const bool pub = strip + 1 < a.nstrips;
-    bool need = strip > 0;
+    bool need = strip > 0 && !(a.ablate & 64);   // timing experiment: nobody waits
+    const bool no_stores = a.ablate & 128;       // timing experiment: the table is not written
     const unsigned long long tag = serial & kWalkTagMask;
     const int nb = a.walk_nbatches;
     // my granules; the left neighbour's are one unit earlier (strip 0 polls its own: ignored)
@@ -882,6 +906,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const Enc
     uint32_t acc[12];  // the table row above, for this lane's 4 pixels (0 above the frame)
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 0;
+    uint32_t slow_polls = 0, spun = 0;  // hand-off waits that took the slow path, their polls
+    const unsigned long long t_start = (a.ablate & 256) ? __builtin_amdgcn_s_memrealtime() : 0;
 
     auto walk_batch = [&](const RowBatch<SRC> &raw, unsigned long long g, int t) {
       const int y = t * kRowUnroll;
@@ -910,7 +936,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const Enc
       uint32_t lin = 0;
       if (need) {
         if (!__all((g >> 24) == tag || lane >= kWalkLanes)) {
-          g = walk_repoll(in + (size_t)t * kWalkLanes, tag, lane);
+          ++slow_polls;
+          g = walk_repoll(in + (size_t)t * kWalkLanes, tag, lane, spun);
           if (!__all((g >> 24) == tag || lane >= kWalkLanes)) {  // gave up: say so, stop waiting
             if (lane == 0)
               __hip_atomic_store(a.walk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -959,7 +986,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const Enc
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int off = k * 256 + lane * 4;
-          if (base + off < row_dwords)  // width % 4 == 0 -> whole 16 B in range
+          if (base + off < row_dwords && !no_stores)  // width % 4 == 0 -> whole 16 B in range
             global_store_b128_uncounted_nt(row + base + off, q[k]);
         }
       }
@@ -968,20 +995,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const Enc
     // DEPTH batches of 8 rows rotate through static buffers, DEPTH - 1 of them in flight.  The
     // poll of batch t is issued BEFORE the pixel loads of batch t + DEPTH - 1, so waiting for
     // it leaves those in flight; every load is unconditional (rows clamped to the last row).
+    // (Consuming the hand-off one iteration AFTER producing it -- scan and publish batch t + 1,
+    // then write the rows of batch t -- was built and measured: 82.3 against 80.3 us per frame,
+    // the waiting path still taken in 60 % of the batches.  Slack does not help: a strip cannot
+    // pass its left neighbour, so the gap between two neighbours is a random walk with a
+    // reflecting barrier, and moving the barrier by one batch moves the walk, not its spread.)
     RowBatch<SRC> buf[DEPTH];
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d)
-      reduce_load_batch<SRC>(a, fr, buf[d], d * kRowUnroll, x0, y_last);
+      walk_load_batch<SRC>(a, fr, buf[d], d * kRowUnroll, x0, y_last);
     for (int t0 = 0; t0 < nb; t0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
         const int t = t0 + d;
         const unsigned long long g = __hip_atomic_load(
             in + (size_t)min(t, nb - 1) * kWalkLanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reduce_load_batch<SRC>(a, fr, buf[(d + DEPTH - 1) % DEPTH], (t + DEPTH - 1) * kRowUnroll,
-                               x0, y_last);
+        walk_load_batch<SRC>(a, fr, buf[(d + DEPTH - 1) % DEPTH], (t + DEPTH - 1) * kRowUnroll,
+                             x0, y_last);
         if (t < nb) walk_batch(buf[d], g, t);
       }
+    }
+    if ((a.ablate & 256) && lane == 0) {
+      // (two 16-byte stores: 8-byte stores are reserved for the hand-off granules, whose sc1
+      // bit the ISA guard checks)
+      ulonglong2 *st = reinterpret_cast<ulonglong2 *>(a.walk_stats + (size_t)unit * 4);
+      st[0] = make_ulonglong2(t_start, __builtin_amdgcn_s_memrealtime());
+      st[1] = make_ulonglong2(slow_polls, spun);
     }
   }
   // retire: the last wave of the launch re-arms the state for the next one
@@ -1291,7 +1330,9 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
     p.walk_err_dev = static_cast<uint32_t *>(d);
   }
   // granules: zeroed when (re)allocated -- a tag is never 0 -- and never again
-  const size_t chain_bytes = (size_t)per_launch * nstrips * nb * kWalkLanes * 8;
+  // (+ 32 bytes per unit behind the granules: the debug statistics of debug.ablate bit 8)
+  const size_t gran_bytes = (size_t)per_launch * nstrips * nb * kWalkLanes * 8;
+  const size_t chain_bytes = gran_bytes + (size_t)per_launch * nstrips * 32;
   if (chain_bytes > p.walk_chain.bytes) {
     if (p.walk_chain.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
     int st = p.walk_chain.reserve(chain_bytes);
@@ -1315,6 +1356,9 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   a.walk = p.walk_state.as<WalkState>();
   a.walk_chain = p.walk_chain.as<unsigned long long>();
   a.walk_err = p.walk_err_dev;
+  a.walk_stats = reinterpret_cast<unsigned long long *>(p.walk_chain.as<uint8_t>() + gran_bytes);
+  p.walk_stats_units = per_launch * nstrips;
+  p.walk_stats_offset = gran_bytes;
   const int yuv_src = !yuvs ? 0 : ctx->opt_yuv_model == 1 ? kSrcYuvSwsX86 : kSrcYuvSwsC;
   const int depth = ctx->opt_walk_depth;
 
@@ -1334,12 +1378,10 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
     f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
 #define F360_WALK_LAUNCH(SRC)                                                                   \
   do {                                                                                          \
-    if (depth == 2)                                                                             \
+    if (depth <= 2)                                                                             \
       hipLaunchKernelGGL((sat_walk_kernel<SRC, 2>), grid, block, 0, ctx->stream, a, wb);        \
-    else if (depth == 3)                                                                        \
-      hipLaunchKernelGGL((sat_walk_kernel<SRC, 3>), grid, block, 0, ctx->stream, a, wb);        \
     else                                                                                        \
-      hipLaunchKernelGGL((sat_walk_kernel<SRC, 4>), grid, block, 0, ctx->stream, a, wb);        \
+      hipLaunchKernelGGL((sat_walk_kernel<SRC, 3>), grid, block, 0, ctx->stream, a, wb);        \
   } while (0)
     if (yuv_src == kSrcYuvSwsX86)
       F360_WALK_LAUNCH(kSrcYuvSwsX86);
@@ -1354,6 +1396,20 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
 }
 
 }  // namespace
+
+// Debug: the per-unit statistics of the last read-once launch that ran with debug.ablate bit 8
+// ({start, end} in 100 MHz ticks, slow-path waits, polls spent in them); returns the unit count.
+extern "C" int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int max_units) {
+  F360_REQUIRE(ctx && out && max_units >= 0, "f360_debug_walk_stats: bad argument");
+  F360_BIND_DEVICE(ctx);
+  const f360::SatEncodePlan &p = ctx->enc;
+  const int n = std::min(max_units, p.walk_stats_units);
+  if (n <= 0 || !p.walk_chain.p) return 0;
+  F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  F360_HIP_TRY(hipMemcpy(out, p.walk_chain.as<uint8_t>() + p.walk_stats_offset, (size_t)n * 32,
+                         hipMemcpyDeviceToHost));
+  return n;
+}
 
 extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev,
                                int width, int height, int linesize) {
@@ -1421,6 +1477,24 @@ extern "C" int f360_sat_encode_yuv420p_batch(f360_ctx *ctx, int count, uint32_t 
   for (int k = 0; k < count; ++k)
     planes[(size_t)k] = f360::YuvPlanes{y_dev[k], u_dev[k], v_dev[k], y_linesize, u_linesize,
                                         v_linesize};
+  // enough frames to fill the device: the read-once encoder, converting in registers as the
+  // three-kernel one does (the same argument rules; anything else takes the old path, whose
+  // checks then report what is wrong)
+  if (walk_wanted(ctx, count, width) && width % 4 == 0 && height % 2 == 0 &&
+      y_linesize >= width && u_linesize >= width / 2 && v_linesize >= width / 2 &&
+      y_linesize % 4 == 0 && u_linesize % 2 == 0 && v_linesize % 2 == 0 &&
+      (size_t)width * height * 3 < ((size_t)1 << 31)) {
+    bool ok = true;
+    for (int k = 0; k < count && ok; ++k)
+      ok = sat_dev[k] && y_dev[k] && u_dev[k] && v_dev[k] && ((uintptr_t)y_dev[k] % 4) == 0 &&
+           ((uintptr_t)u_dev[k] % 2) == 0 && ((uintptr_t)v_dev[k] % 2) == 0 &&
+           ((uintptr_t)sat_dev[k] % 16) == 0;
+    if (ok) {
+      F360_BIND_DEVICE(ctx);
+      return sat_encode_walk(ctx, count, sat_dev, nullptr, planes.data(), width, height, 0,
+                             prof != 0);
+    }
+  }
   for (int k = 0; k < count; k += per_launch) {
     const int n = std::min(count - k, per_launch);
     const int st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, 0, nullptr, nullptr,

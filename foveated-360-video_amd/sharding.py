@@ -34,3 +34,17 @@ def reduce_run(elapsed_s: float, pixels: float, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(p, op=dist.ReduceOp.SUM)
     return float(t.item()), float(p.item())
+
+
+def gather_run(elapsed_s: float, frames: int, device=None):
+    """[(rank, frames, elapsed)] of every rank, on every rank (one all_gather of two doubles):
+    the benchmark prints it as `per_rank` so a straggler is visible.  Identity when not
+    distributed."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [(0, int(frames), float(elapsed_s))]
+    mine = torch.tensor([float(frames), elapsed_s], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [(r, int(t[0].item()), float(t[1].item())) for r, t in enumerate(out)]

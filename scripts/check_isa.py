@@ -128,11 +128,15 @@ def main():
                 # table stores, write-through granule stores, an sc1 poll, and a steady-state
                 # loop whose only drain is the slow path of a hand-off wait (it follows its own
                 # sc1 load directly)
-                if re.search(r"sat_walk_kernelILi[123]ELi[234]EE", name):
+                if re.search(r"sat_walk_kernelILi[123]ELi[23]EE", name):
                     seen.add("walker")
                     if any(t.startswith(("scratch_", "s_swappc")) for t in texts):
                         perf.append(f"{name}: scratch memory or a call in the strip walker")
-                    if any(t.startswith("global_store_dwordx4") and " nt" not in t for t in texts):
+                    # (the debug statistics behind the last table store are plain stores)
+                    nts = [i for i, t in enumerate(texts)
+                           if t.startswith("global_store_dwordx4") and " nt" in t]
+                    if len(nts) < 24 or any(t.startswith("global_store_dwordx4") and " nt" not in t
+                                            for t in texts[nts[0]:nts[-1] + 1]):
                         perf.append(f"{name}: a table store lost its nt bit")
                     gran = [t for t in texts if t.startswith("global_store_dwordx2")]
                     if not gran or any(" sc1" not in t for t in gran):
@@ -142,7 +146,7 @@ def main():
                         errors.append(f"{name}: hand-off polls must be sc1 loads")
                     # between the first and the last table store the only full drains allowed
                     # are the slow path's (each directly behind its own sc1 poll load)
-                    st = [i for i, t in enumerate(texts) if t.startswith("global_store_dwordx4")]
+                    st = nts
                     if st:
                         body = texts[st[0]:st[-1] + 1]
                         bad = [i for i, t in enumerate(body) if t.startswith("s_waitcnt vmcnt(0)")

@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=3840)
     ap.add_argument("--counts", default="16,32,64")
-    ap.add_argument("--depths", default="2,3,4")
+    ap.add_argument("--depths", default="2,3")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
