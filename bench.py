@@ -128,6 +128,19 @@ def launch_plan(gpus, batch, global_batch):
     return [range(r * batch, (r + 1) * batch) for r in range(gpus)]
 
 
+def encoder_plan(width, frames_per_call, opts):
+    """Which encoder an EncodeFramesGPU call of `frames_per_call` frames takes (the library's
+    rule, sat_encode.hip walk_wanted): the read-once strip walker needs frames x strips >=
+    sat.walk_units (960: 32 frames at 8K) to fill the device, below that the three kernels run."""
+    o = dict(kv.split("=") for kv in opts)
+    walk, units = int(o.get("sat.walk", -1)), int(o.get("sat.walk_units", 960))
+    if frames_per_call <= 1 or walk == 0:
+        return "three kernels (reduce, carry, write)"
+    if walk == 1 or frames_per_call * ((width + 255) // 256) >= units:
+        return "read-once (sat_walk_kernel)"
+    return "three kernels (reduce, carry, write)"
+
+
 def self_launch(args, argv):
     """--gpus N > 1 without a launcher: run N fresh ranks under torch.distributed.run as a child
     process.  The parent has not imported torch or made any GPU call, and it never execs."""
@@ -206,7 +219,10 @@ def main():
         print(json.dumps({
             "gpus": args.gpus, "scaling": "strong" if args.global_batch else "weak",
             "frames_total": sum(len(r) for r in plan),
-            "ranks": [{"rank": r, "frames": [rg.start, rg.stop]} for r, rg in enumerate(plan)],
+            "ranks": [{"rank": r, "frames": [rg.start, rg.stop],
+                       "frames_per_call": min(args.frames_per_call, len(rg)),
+                       "encoder": encoder_plan(args.width, min(args.frames_per_call, len(rg)), args.opt)}
+                      for r, rg in enumerate(plan)],
             "launch": (self_launch(args, argv) if args.gpus > 1 and not launched
                        else [sys.executable, os.path.abspath(__file__)] + argv)}))
         return

@@ -11,7 +11,7 @@
 // (instead of NVENC + fMP4 + websocket).  Reports per-frame busy latency (everything but
 // the sleep) and aggregate input Mpixels/s: BASELINE.json config 5.
 //
-//   ./send_frame_loop_synth <clients> <fps> <frames> <width> <height> [trace.txt] [gpus]
+//   ./send_frame_loop_synth <clients> <fps> <frames> <width> <height> [trace.txt] [gpus] [rgb0|yuv420p in] [rgb0|yuv420p out] [plan]
 //                           [rgb0|yuv420p (source layout)] [rgb0|yuv420p (delivered layout)]
 // client c runs on GPU c % gpus.  Prints one JSON line.  With "yuv420p" as the delivered layout
 // the reduced frame is converted on the device (f360_rgb0_to_yuv420p, the sws_scale of
@@ -183,6 +183,29 @@ int main(int argc, char **argv) {
   int gpus = argc > 7 ? atoi(argv[7]) : 0;
   const bool planar = argc > 8 && std::string(argv[8]) == "yuv420p";
   const bool planar_out = argc > 9 && std::string(argv[9]) == "yuv420p";
+  // "plan" as the 10th argument: print which device every client's thread would open and
+  // what it would allocate there, without touching a GPU (the 8-GPU form of config 5 --
+  // client c <-> GPU c, src/video_server.cc:62-66 -- can be checked on a box without eight)
+  const bool plan_only = argc > 10 && std::string(argv[10]) == "plan";
+  if (plan_only) {
+    if (gpus <= 0) {
+      std::cerr << "plan: the GPU count must be given explicitly" << std::endl;
+      return EXIT_FAILURE;
+    }
+    const int rw = 16 * (int)std::ceil(width / 1.8 / 16), rh = 16 * (int)std::ceil(height / 1.8 / 16);
+    const size_t in_bytes = planar ? (size_t)width * height * 3 / 2 : (size_t)width * height * 4;
+    const size_t out_bytes = planar_out ? (size_t)rw * rh * 3 / 2 : (size_t)rw * rh * 4;
+    printf("{\"plan\": true, \"clients\": %d, \"gpus\": %d, \"client_device\": [", clients, gpus);
+    for (int c = 0; c < clients; ++c) printf("%s%d", c ? ", " : "", c % gpus);
+    printf("], \"clients_per_device\": [");
+    for (int g = 0; g < gpus; ++g)
+      printf("%s%d", g ? ", " : "", clients / gpus + (g < clients % gpus ? 1 : 0));
+    printf("], \"reduced\": [%d, %d], \"device_bytes_per_client\": %zu, "
+           "\"upload_bytes_per_frame\": %zu, \"download_bytes_per_frame\": %zu}\n",
+           rw, rh, in_bytes + (size_t)width * height * 12 + (size_t)rw * rh * 4 + out_bytes, in_bytes,
+           out_bytes);
+    return EXIT_SUCCESS;
+  }
   if (gpus <= 0 && f360_device_count(&gpus) != F360_OK) {
     std::cerr << f360_last_error_string() << std::endl;
     return EXIT_FAILURE;

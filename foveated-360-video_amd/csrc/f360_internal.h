@@ -151,6 +151,7 @@ struct f360_ctx {
   int opt_stream_rows = 8;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64
   int opt_stream_depth = 2;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 3 | 5)
   int opt_stream_spread = 0;   // "sample.spread": consecutive streamer waves take tiles a quarter of the row apart instead of neighbouring ones
+  int opt_sample_fpl = 16;     // "sample.fpl": frames per launch of f360_satdec_sample_rect_frames (1..64)
   int opt_batch_mb = 180;      // "sat.batch_mb": source bytes (MB) a batched encoder launch may cover
   int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows
   int opt_walk_units = 960;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder

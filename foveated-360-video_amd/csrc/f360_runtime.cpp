@@ -270,6 +270,7 @@ static const OptionSlot kOptions[] = {
     {"sample.spread", &f360_ctx::opt_stream_spread},
     {"sample.groups", &f360_ctx::opt_stream_groups},
     {"sat.batch_mb", &f360_ctx::opt_batch_mb},
+    {"sample.fpl", &f360_ctx::opt_sample_fpl},
     {"sat.walk", &f360_ctx::opt_walk},
     {"sat.walk_units", &f360_ctx::opt_walk_units},
     {"sat.walk_depth", &f360_ctx::opt_walk_depth},
@@ -308,6 +309,8 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
         F360_REQUIRE(value >= 2 && value <= 3, "sat.walk_depth must be 2 or 3: %d", value);
       if (s.field == &f360_ctx::opt_walk_units)
         F360_REQUIRE(value >= 1, "sat.walk_units must be >= 1: %d", value);
+      if (s.field == &f360_ctx::opt_sample_fpl)
+        F360_REQUIRE(value >= 1 && value <= 64, "sample.fpl out of range 1..64: %d", value);
       if (s.field == &f360_ctx::opt_sample_variant)
         F360_REQUIRE(value >= 0 && value <= 2, "sample.variant must be 0, 1 or 2: %d", value);
       ctx->*(s.field) = value;

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void sample_rect_walk_kernel(const SampleArgs 
 
 // Several gaze points against ONE table (clients that watch the same video share the
 // encode): blockIdx.z selects the client.
-constexpr int kMaxBatch = 16;
+constexpr int kMaxBatch = 64;    // frames (or gaze points) one launch can take
+constexpr int kMaxClients = 16;  // f360_satdec_sample_rect_batch's documented limit
 struct SampleBatch {
   uint8_t *dst[kMaxBatch];
   const uint32_t *sat[kMaxBatch];  // the same table for every client, or one per frame
@@ -1068,6 +1069,8 @@ int f360_satdec_sample_rect_batch(f360_sat_decoder *dec, uint8_t *const *targets
                                   int source_width, int source_height,
                                   const float *centers_xy) {
   F360_REQUIRE(sat_dev, "f360_satdec_sample_rect_batch: null table");
+  F360_REQUIRE(count <= kMaxClients, "f360_satdec_sample_rect_batch: count %d outside 1..%d", count,
+               kMaxClients);
   return sample_rect_batch_impl(dec, targets_dev, count, target_width, target_height,
                                 target_linesize, sat_dev, nullptr, source_width, source_height,
                                 centers_xy);
@@ -1080,9 +1083,10 @@ int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *target
                                    const float *centers_xy) {
   F360_REQUIRE(dec && sats_dev && count >= 1, "f360_satdec_sample_rect_frames: bad arguments");
   const int prof = f360::take_profile_slot(dec->ctx) ? 1 : 0;  // one slot for the whole call
-  // more frames than one launch holds: consecutive launches
-  for (int k = 0; k < count; k += kMaxBatch) {
-    const int n = std::min(count - k, kMaxBatch);
+  // more frames than one launch takes ("sample.fpl", at most 64): consecutive launches
+  const int per_launch = std::min(std::max(dec->ctx->opt_sample_fpl, 1), kMaxBatch);
+  for (int k = 0; k < count; k += per_launch) {
+    const int n = std::min(count - k, per_launch);
     const int st = sample_rect_batch_impl(dec, targets_dev + k, n, target_width, target_height,
                                           target_linesize, nullptr, sats_dev + k, source_width,
                                           source_height, centers_xy + 2 * k, prof);

@@ -3,7 +3,9 @@
 output directories) and stamps it with the hash of the kernel sources it was measured on:
 bench.py reports `roofline.traffic` only while that hash matches the tree it runs from.
 
-    python scripts/pmc_traffic.py <out.json> <pmc dir with FETCH_SIZE> <pmc dir with WRITE_SIZE> [yuv dirs...]
+    python scripts/pmc_traffic.py <out.json> <pmc dir(s) with FETCH_SIZE> <pmc dir(s) with WRITE_SIZE> [yuv dirs...]
+    (a "dir" may be several directories joined with ':' -- the default command's passes and the
+    one-frame-per-call passes)
     python scripts/pmc_traffic.py --hash          # the hash of the current csrc/
 """
 import csv
@@ -28,9 +30,12 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def means(path, counter):
+def means(paths, counter):
     acc = {}
-    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+    files = []
+    for path in paths.split(":"):
+        files += glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+    for f in files:
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
@@ -54,23 +59,31 @@ def main():
                      "(confirmed on the reducer: 57.7 MB reported for a 118 MB frame); WRITE_SIZE as "
                      "is.  bench.py uses it only while csrc_sha equals the hash of its own csrc/."),
            "csrc_sha": csrc_hash()}
-    # (instantiation measured, key in the file, FETCH_SIZE factor): RGB0 source = 1, table
-    # writer with LDS-staged stores = 1; tile streamer with a ring of 3 slots, byte stores
-    for inst, kernel, dbl in (("sat_write_kernel<1, 1>", "sat_write_kernel", 2),
-                              ("sat_reduce_kernel<1>", "sat_reduce_kernel", 2),
-                              ("sat_carry_kernel", "sat_carry_kernel", 2),
-                              ("sample_rect_stream_kernel<3, false>", "sample_rect_kernel", 2)):
-        if inst in fetch and inst in write:
-            doc[kernel] = {size: int(1024 * (dbl * fetch[inst] + write[inst])),
-                           "_fetch_kb": round(fetch[inst], 1), "_write_kb": round(write[inst], 1),
-                           "_instance": inst}
+    # (instantiation measured, key in the file, FETCH_SIZE factor, frames one launch covered):
+    # the default command's kernels first -- the read-once encoder with 64 frames per launch, the
+    # batch tile streamer with 16 --, then the single-frame kernels (--frames-per-call 1 passes);
+    # an entry is per FRAME (per-launch counters divided by the frames of the launch), bench.py
+    # multiplies by the frames its own launches cover.  RGB0 source = 1, LDS-staged stores = 1,
+    # ring of 3 slots, byte stores.
+    for inst, kernel, dbl, fpl in (("sat_walk_kernel<1, 2>", "sat_walk_kernel", 2, 64),
+                                   ("sample_rect_stream_batch_kernel<3>", "sample_rect_kernel", 2, 16),
+                                   ("sat_write_kernel<1, 1>", "sat_write_kernel", 2, 1),
+                                   ("sat_reduce_kernel<1>", "sat_reduce_kernel", 2, 1),
+                                   ("sat_carry_kernel", "sat_carry_kernel", 2, 1),
+                                   ("sample_rect_stream_kernel<3, false>", "sample_rect_kernel", 2, 1)):
+        if inst in fetch and inst in write and kernel not in doc:
+            doc[kernel] = {size: int(1024 * (dbl * fetch[inst] + write[inst]) / fpl),
+                           "_fetch_kb": round(fetch[inst] / fpl, 1),
+                           "_write_kb": round(write[inst] / fpl, 1),
+                           "_instance": inst, "_frames_per_launch": fpl}
     if len(sys.argv) >= 6:
         yf, yw = means(sys.argv[4], "FETCH_SIZE"), means(sys.argv[5], "WRITE_SIZE")
         # planar source, x86 rounding model = 3
-        for inst, kernel in (("sat_write_kernel<3, 1>", "sat_write_kernel"),
-                             ("sat_reduce_kernel<3>", "sat_reduce_kernel")):
+        for inst, kernel, fpl in (("sat_walk_kernel<3, 2>", "sat_walk_kernel", 64),
+                                  ("sat_write_kernel<3, 1>", "sat_write_kernel", 1),
+                                  ("sat_reduce_kernel<3>", "sat_reduce_kernel", 1)):
             if inst in yf and inst in yw:
-                doc.setdefault(kernel, {})[size + ":yuv420p"] = int(1024 * (2 * yf[inst] + yw[inst]))
+                doc.setdefault(kernel, {})[size + ":yuv420p"] = int(1024 * (2 * yf[inst] + yw[inst]) / fpl)
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc))

@@ -21,7 +21,9 @@ def dry(*args, env=None):
 def test_single_gpu_plan_is_the_plain_command():
     plan = dry()
     assert plan["gpus"] == 1 and plan["scaling"] == "weak"
-    assert plan["ranks"] == [{"rank": 0, "frames": [0, 64]}]
+    assert [(r["rank"], r["frames"]) for r in plan["ranks"]] == [(0, [0, 64])]
+    # 64 frames per encode call fill the device: the read-once encoder
+    assert plan["ranks"][0]["frames_per_call"] == 64 and "read-once" in plan["ranks"][0]["encoder"]
     assert plan["launch"][1:] == [BENCH]          # no launcher around N = 1
 
 
@@ -29,6 +31,9 @@ def test_global_batch_64_over_8_gpus_is_8_frames_each():
     plan = dry("--gpus", "8", "--global-batch", "64", "--steps", "5", "--warmup", "2")
     assert plan["scaling"] == "strong" and plan["frames_total"] == 64
     assert [r["frames"] for r in plan["ranks"]] == [[8 * k, 8 * k + 8] for k in range(8)]
+    # 8 frames per rank = 240 strips: too few for the strip walker, the three kernels take them
+    assert all(r["frames_per_call"] == 8 and r["encoder"].startswith("three kernels")
+               for r in plan["ranks"])
     cmd = plan["launch"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
@@ -64,3 +69,27 @@ def test_parent_plans_without_importing_torch():
             "assert 'torch' not in sys.modules, 'the launching parent imported torch'" % BENCH)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
+
+
+def test_send_frame_loop_plan_maps_client_c_to_gpu_c():
+    """Config 5's 8-GPU form (client c <-> GPU c, src/video_server.cc:62-66), plan-checked without
+    a GPU: examples/send_frame_loop_synth ... plan prints the device every client's thread opens."""
+    ex = os.path.join(REPO, "examples")
+    out = subprocess.run(["make", "-C", ex, "send_frame_loop_synth"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    exe = os.path.join(ex, "send_frame_loop_synth")
+
+    def plan(*a):
+        o = subprocess.run([exe, *a], capture_output=True, text=True, timeout=60)
+        assert o.returncode == 0, o.stderr
+        return json.loads(o.stdout)
+    p = plan("8", "60", "120", "7680", "3840", "", "8", "rgb0", "rgb0", "plan")
+    assert p["client_device"] == list(range(8)) and p["clients_per_device"] == [1] * 8
+    assert p["reduced"] == [4272, 2144] and p["upload_bytes_per_frame"] == 7680 * 3840 * 4
+    p = plan("8", "60", "120", "7680", "3840", "", "3", "yuv420p", "yuv420p", "plan")
+    assert p["client_device"] == [0, 1, 2, 0, 1, 2, 0, 1] and p["clients_per_device"] == [3, 3, 2]
+    assert p["upload_bytes_per_frame"] == 7680 * 3840 * 3 // 2
+    o = subprocess.run([exe, "8", "60", "120", "7680", "3840", "", "0", "rgb0", "rgb0", "plan"],
+                       capture_output=True, text=True, timeout=60)
+    assert o.returncode != 0  # the plan needs an explicit GPU count
