@@ -144,6 +144,8 @@ _SIGNATURES = {
     "f360_ctx_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "f360_ctx_profile_frames": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "f360_debug_walk_stats": (c_int, [c_void_p, c_void_p, c_int]),
+    "f360_debug_cr_math": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
     "f360_ctx_profile_reset": (c_int, [c_void_p]),
     "f360_tables_satdec_grid_axis": (c_int, [c_void_p, c_int, c_int]),
     "f360_tables_is_grid_axis": (c_int, [c_void_p, c_int, c_int]),

@@ -162,7 +162,8 @@ struct f360_ctx {
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
-  int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table
+  int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos), 2 two planes (sin, cos)
+  int opt_gnomonic_fast = 1;   // "gnomonic.fast": asin / atan2 through cr_math.h (cheap double evaluation + rounding guard, library routine for the rejected lanes)
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
@@ -170,7 +171,7 @@ struct f360_ctx {
   int ex_w = 0, ex_h = 0, ex_tw = 0, ex_th = 0, ex_kind = -1;
   f360::DevBuf ex_tables, ex_keys;
   // gnomonic remap: view-independent per-pixel terms of one target geometry (projections.hip)
-  int gn_w = 0, gn_h = 0;
+  int gn_w = 0, gn_h = 0, gn_kind = 0;
   f360::DevBuf gn_table;
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;

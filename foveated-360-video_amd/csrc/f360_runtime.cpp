@@ -280,6 +280,7 @@ static const OptionSlot kOptions[] = {
     {"yuv.model", &f360_ctx::opt_yuv_model},
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
+    {"gnomonic.fast", &f360_ctx::opt_gnomonic_fast},
     {"is.lp_table", &f360_ctx::opt_lp_table},
 };
 
