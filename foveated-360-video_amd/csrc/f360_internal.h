@@ -148,7 +148,7 @@ struct f360_ctx {
   int opt_store_mode = 1;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-staged contiguous stores
   int opt_sample_variant = 2;  // "sample.variant": 0 per-pixel, 1 column walker, 2 tile streamer (falls back to the walker where it does not apply)
   int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker
-  int opt_stream_rows = 8;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64
+  int opt_stream_rows = 0;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64; 0 = by size (4 for a single small frame, else 8)
   int opt_stream_depth = 2;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 3 | 5)
   int opt_stream_spread = 0;   // "sample.spread": consecutive streamer waves take tiles a quarter of the row apart instead of neighbouring ones
   int opt_sample_fpl = 16;     // "sample.fpl": frames per launch of f360_satdec_sample_rect_frames (1..64)
@@ -163,7 +163,7 @@ struct f360_ctx {
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos), 2 two planes (sin, cos)
-  int opt_gnomonic_fast = 1;   // "gnomonic.fast": asin / atan2 through cr_math.h (cheap double evaluation + rounding guard, library routine for the rejected lanes)
+  int opt_gnomonic_fast = 0;   // "gnomonic.fast": asin / atan2 through cr_math.h (cheap double evaluation + rounding guard, library routine for the rejected lanes)
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the

@@ -300,7 +300,7 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
       if (s.field == &f360_ctx::opt_walk_rows)
         F360_REQUIRE(value >= 1 && value <= 4096, "sample.rows out of range: %d", value);
       if (s.field == &f360_ctx::opt_stream_rows)
-        F360_REQUIRE(value >= 1 && value <= 64, "sample.srows out of range 1..64: %d", value);
+        F360_REQUIRE(value >= 0 && value <= 64, "sample.srows out of range 0..64: %d", value);
       if (s.field == &f360_ctx::opt_stream_depth)
         F360_REQUIRE(value == 2 || value == 3 || value == 5, "sample.depth must be 2, 3 or 5: %d",
                      value);

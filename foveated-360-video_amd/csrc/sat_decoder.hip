@@ -936,7 +936,12 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   if (variant == 2 && can_stream) {
     const int ntiles = (source_width + kTsTile - 1) / kTsTile;
     if (fits) {
-      const int rows = std::min(ctx->opt_stream_rows, kTsMaxRows);
+      // reduced rows per wave ("sample.srows", 0 = by size): a single small frame cannot fill
+      // the device with 8-row runs (1080p -> 608 rows: 76 runs x 15 tiles), 4-row runs double
+      // the waves (13.6 -> 11.7 us at 1080p, 15.1 -> 14.2 at 2560x1440, nothing at 3840x1920)
+      const int rows = std::min(ctx->opt_stream_rows > 0 ? ctx->opt_stream_rows
+                                : (long)target_height * ((source_width + kTsTile - 1) / kTsTile) < 20000 ? 4 : 8,
+                                kTsMaxRows);
       const int nblocks = (target_height + rows - 1) / rows;
       int istride = ctx->opt_stream_spread ? std::max(ntiles / 4, 1) : 1;
       while (std::gcd(istride, ntiles) != 1) ++istride;
@@ -1039,7 +1044,7 @@ static int sample_rect_batch_impl(f360_sat_decoder *dec, uint8_t *const *targets
              tile_stream_fits(dec, b.cxp[k], source_width, target_width);
   if (stream) {
     const int ntiles = (source_width + kTsTile - 1) / kTsTile;
-    const int rows = std::min(ctx->opt_stream_rows, kTsMaxRows);
+    const int rows = std::min(ctx->opt_stream_rows > 0 ? ctx->opt_stream_rows : 8, kTsMaxRows);
     const int nblocks = (target_height + rows - 1) / rows;
     const dim3 sgrid((unsigned)((ntiles * nblocks + 3) / 4), (unsigned)count);
     if (ctx->opt_stream_depth <= 2)

@@ -1060,7 +1060,10 @@ int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false, int f
   // (with 64-row bands one band per reducer wave also makes the reducer visit the frame in the
   // writer's tile order, and the writer's re-read then finds more of it in the caches: 80 -> 76 us
   // at 8K for +1.7 us in the carry kernel; with 16-row bands two bands per wave stay better)
-  if (sb_bands < 0) sb_bands = (planar || band_rows == 64) ? 1 : 2;
+  // (a small frame has too few reducer waves to fill the device with two bands each: 1080p
+  // 272 waves of 32 rows against 544 of 16 -- reducer 11.6 -> 8.4 us, 11.8 -> 9.0 at 2560x1440)
+  if (sb_bands < 0)
+    sb_bands = (planar || band_rows == 64 || (long)width * height <= 4200000L) ? 1 : 2;
   if (sb_bands == 0) {
     const int nb = (height + band_rows - 1) / band_rows;
     sb_bands = (nb + 31) / 32;
@@ -1310,7 +1313,10 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   f360::SatEncodePlan &p = ctx->enc;
   const int nstrips = (width + kStripPx - 1) / kStripPx;
   const int nb = (height + kRowUnroll - 1) / kRowUnroll;
-  const int per_launch = std::min(count, kWalkFrames);
+  // launches of equal size (65 frames: 33 + 32, not 64 + 1 -- a launch of one frame would be 30
+  // strip owners on an empty device)
+  const int nlaunch = (count + kWalkFrames - 1) / kWalkFrames;
+  const int per_launch = (count + nlaunch - 1) / nlaunch;
   // state words: zero ticket / done, serial 1; the launches advance them
   if (!p.walk_state.p) {
     int st = p.walk_state.reserve(64);

@@ -93,5 +93,5 @@ def test_gnomonic_is_bit_exact_for_every_table_and_path(f360, gpu_ctx, oracle, f
             src.free()
             dst.free()
     finally:
-        gpu_ctx.set_option("gnomonic.fast", 1)
+        gpu_ctx.set_option("gnomonic.fast", 0)
         gpu_ctx.set_option("gnomonic.table", 1)

@@ -180,3 +180,17 @@ def test_walk_encode_from_planes(f360, walk_ctx, oracle, model, w, h, pad, n):
     for b in sats + [p for t in dev for p in t]:
         b.free()
     assert bad == []
+
+
+def test_config4_batch_through_the_automatic_choice(f360, oracle):
+    """BASELINE config 4 the way bench.py runs it: 32 of its frames (31 LCG frames + the all-255
+    frame whose sums wrap mod 2^32) resident, one EncodeFramesGPU call -- 960 strips: the
+    automatic choice takes the read-once encoder -- and one SampleFramesRectGPU call; every
+    table and every reduced frame equals the oracle's by digest."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_configs
+    res = bench_configs.config4_batched(f360, oracle, quick=True)
+    assert "sat_walk_kernel" in res["workload"], res
+    assert res["bad_frames"] == [], res
