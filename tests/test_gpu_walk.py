@@ -194,3 +194,41 @@ def test_config4_batch_through_the_automatic_choice(f360, oracle):
     res = bench_configs.config4_batched(f360, oracle, quick=True)
     assert "sat_walk_kernel" in res["workload"], res
     assert res["bad_frames"] == [], res
+
+
+def test_two_walker_launches_share_the_device(f360, oracle):
+    """Two contexts (two streams) run read-once launches at the same time: workgroups of one
+    launch occupy SIMDs the other's later tickets are waiting for.  A strip only ever waits for a
+    unit whose workgroup is already running, so both drain and both are right."""
+    import threading
+    w, h, n = 2304, 200, 40   # 9 strips x 40 frames = 360 units per launch
+    results = {}
+
+    def worker(tag, seed):
+        with f360.Context(0) as ctx:
+            ctx.set_option("sat.walk", 1)
+            frames = [oracle.lcg_frame(w, h, seed + k) for k in range(n)]
+            srcs = [ctx.upload(f) for f in frames]
+            sats = [ctx.malloc(w * h * 12) for _ in range(n)]
+            enc = f360.SATEncoder(ctx)
+            bad = []
+            for rep in range(5):
+                for s in sats:
+                    s.fill(rep + 1)
+                enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, 4 * w)
+                enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, 4 * w)
+                ctx.finish()
+                for k in (0, n // 2, n - 1):
+                    if not np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)),
+                                          oracle.sat_encode(frames[k], w, h, 4 * w)):
+                        bad.append((rep, k))
+            for b in srcs + sats:
+                b.free()
+            results[tag] = bad
+
+    threads = [threading.Thread(target=worker, args=(t, 500 + 100 * t)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert results == {0: [], 1: []}, results
