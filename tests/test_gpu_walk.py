@@ -232,3 +232,54 @@ def test_two_walker_launches_share_the_device(f360, oracle):
     for t in threads:
         t.join()
     assert results == {0: [], 1: []}, results
+
+
+def test_walker_launch_replays_from_a_hip_graph(f360, oracle):
+    """Nothing a read-once launch needs comes from the host per launch -- ticket, retirement count
+    and the serial that tags its hand-off granules live in device memory and are advanced by the
+    launches themselves -- so a captured launch (kernel arguments frozen) replays correctly, any
+    number of times, on new inputs."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test without a GPU")
+    w, h, n = 1280, 72, 6
+    dev = torch.device("cuda", 0)
+    frames = torch.zeros((n, h, 4 * w), dtype=torch.uint8, device=dev)
+    sats = [torch.zeros((h, w, 3), dtype=torch.int32, device=dev) for _ in range(n)]
+    side = torch.cuda.Stream(dev)
+
+    def put(seed):
+        host = [oracle.lcg_frame(w, h, seed + k) for k in range(n)]
+        for k in range(n):
+            frames[k].copy_(torch.from_numpy(host[k]).to(dev).reshape(h, 4 * w))
+        return host
+
+    with torch.cuda.stream(side):
+        ctx = f360.Context(0, stream=side.cuda_stream)
+        ctx.set_option("sat.walk", 1)
+        enc = f360.SATEncoder(ctx)
+        fp = [frames[k].data_ptr() for k in range(n)]
+        sp = [s.data_ptr() for s in sats]
+        put(10)
+        enc.EncodeFramesGPU(sp, fp, w, h, 4 * w)   # eager warm-up: allocates the hand-off buffers
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            enc.EncodeFramesGPU(sp, fp, w, h, 4 * w)
+        for rep in range(4):
+            host = put(100 * (rep + 1))
+            for s in sats:
+                s.fill_(-1)
+            torch.cuda.synchronize(dev)
+            g.replay()
+            torch.cuda.synchronize(dev)
+            for k in range(n):
+                assert np.array_equal(sats[k].cpu().numpy().view(np.uint32),
+                                      oracle.sat_encode(host[k], w, h, 4 * w)), (rep, k)
+        # and an eager launch after the replays still finds its state in order
+        host = put(999)
+        enc.EncodeFramesGPU(sp, fp, w, h, 4 * w)
+        side.synchronize()
+        assert np.array_equal(sats[n - 1].cpu().numpy().view(np.uint32),
+                              oracle.sat_encode(host[n - 1], w, h, 4 * w))
+    ctx.close()
