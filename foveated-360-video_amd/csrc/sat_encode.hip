@@ -802,6 +802,10 @@ struct WalkState {
   unsigned long long serial;  // launch number = tag of this launch's granules; never 0
 };
 constexpr int kWalkFrames = 64;              // frames per launch
+#ifndef F360_WALK_WAVES
+#define F360_WALK_WAVES 4
+#endif
+constexpr int kWalkWaves = F360_WALK_WAVES;  // strip owners (consecutive units) per workgroup
 constexpr int kWalkLanes = 3 * kRowUnroll;   // granules per batch: 8 rows x 3 channels
 constexpr uint32_t kWalkSpinLimit = 1u << 20;
 constexpr unsigned long long kWalkTagMask = (1ull << 40) - 1;
@@ -863,20 +867,20 @@ __device__ __forceinline__ void walk_load_batch(const EncodeArgs &a, const Encod
 }
 
 template <int SRC, int DEPTH>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const EncodeArgs a,
+__global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeArgs a,
                                                                        const WalkBatch wb) {
   // one LDS object: the waves' 3 KiB store-staging slices, then the workgroup's ticket
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock * 3 * kStripPx + 4];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kWalkWaves * 3 * kStripPx + 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  uint32_t *wg_ticket = stage + kWavesPerBlock * 3 * kStripPx;
+  uint32_t *wg_ticket = stage + kWalkWaves * 3 * kStripPx;
   if (threadIdx.x == 0)
     *wg_ticket = __hip_atomic_fetch_add(&a.walk->ticket, 1u, __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const unsigned long long serial = a.walk->serial;  // written by the previous launch
   const int unit =
-      __builtin_amdgcn_readfirstlane((int)(*wg_ticket * (uint32_t)kWavesPerBlock) + wave);
+      __builtin_amdgcn_readfirstlane((int)(*wg_ticket * (uint32_t)kWalkWaves) + wave);
   if (unit < a.walk_units) {
     const int f = unit / a.nstrips;
     const int strip = unit - f * a.nstrips;
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_walk_kernel(const Enc
   }
   // retire: the last wave of the launch re-arms the state for the next one
   if (lane == 0) {
-    const uint32_t waves = gridDim.x * kWavesPerBlock;
+    const uint32_t waves = gridDim.x * kWalkWaves;
     const uint32_t before = __hip_atomic_fetch_add(&a.walk->done, 1u, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
     if (before == waves - 1) {
@@ -1315,7 +1319,15 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   const int nb = (height + kRowUnroll - 1) / kRowUnroll;
   // launches of equal size (65 frames: 33 + 32, not 64 + 1 -- a launch of one frame would be 30
   // strip owners on an empty device)
-  const int nlaunch = (count + kWalkFrames - 1) / kWalkFrames;
+  // Frames per launch ("sat.walk_frames", 0 = automatic): one workgroup per CU -- one strip owner
+  // per SIMD -- is the sweet spot (32 frames at 8K: 78.4 us per frame against 82.8 for 64 in one
+  // launch on the same box: with two owners per SIMD the per-batch jitter that the hand-off
+  // chain accumulates is five times larger), so a larger call runs as
+  // several launches of about 1024 units, never fewer units than the call's own frames allow.
+  const int strips = (width + kStripPx - 1) / kStripPx;
+  int max_frames = ctx->opt_walk_frames > 0 ? ctx->opt_walk_frames : std::max(1024 / strips, 1);
+  max_frames = std::min(max_frames, kWalkFrames);
+  const int nlaunch = (count + max_frames - 1) / max_frames;
   const int per_launch = (count + nlaunch - 1) / nlaunch;
   // state words: zero ticket / done, serial 1; the launches advance them
   if (!p.walk_state.p) {
@@ -1379,8 +1391,8 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
       wb.v[k] = yuvs ? yuvs[q].v : nullptr;
     }
     a.walk_units = n * nstrips;
-    const dim3 grid((a.walk_units + kWavesPerBlock - 1) / kWavesPerBlock);
-    const dim3 block(64 * kWavesPerBlock);
+    const dim3 grid((a.walk_units + kWalkWaves - 1) / kWalkWaves);
+    const dim3 block(64 * kWalkWaves);
     f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
 #define F360_WALK_LAUNCH(SRC)                                                                   \
   do {                                                                                          \
