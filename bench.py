@@ -176,8 +176,8 @@ def main():
                     help="two-call path: N frames per EncodeFramesGPU / EncodeFramesYUV420PGPU call, then one "
                          "SampleFramesRectGPU call for their N tables.  With enough frames to fill the "
                          "device (960 strips: 32 frames at 8K) the encode call takes the read-once "
-                         "encoder (one launch, sat_walk_kernel), below that the three-kernel one; the "
-                         "sampler shares launches of 16.  1 = EncodeFrameGPU + SampleFrameRectGPU "
+                         "encoder (sat_walk_kernel, launches of about 1024 strips), below that the "
+                         "three-kernel one; the sampler shares launches of 16.  1 = EncodeFrameGPU + SampleFrameRectGPU "
                          "per frame, the reference's own loop (also reported: "
                          "value_reference_call_shape)")
     ap.add_argument("--streams", type=int, default=1,

@@ -60,12 +60,12 @@ def main():
                      "is.  bench.py uses it only while csrc_sha equals the hash of its own csrc/."),
            "csrc_sha": csrc_hash()}
     # (instantiation measured, key in the file, FETCH_SIZE factor, frames one launch covered):
-    # the default command's kernels first -- the read-once encoder with 64 frames per launch, the
-    # batch tile streamer with 16 --, then the single-frame kernels (--frames-per-call 1 passes);
+    # the default command's kernels first -- the read-once encoder (a step's 64 frames in two
+    # launches of 32), the batch tile streamer with 16 --, then the single-frame kernels (--frames-per-call 1 passes);
     # an entry is per FRAME (per-launch counters divided by the frames of the launch), bench.py
     # multiplies by the frames its own launches cover.  RGB0 source = 1, LDS-staged stores = 1,
     # ring of 3 slots, byte stores.
-    for inst, kernel, dbl, fpl in (("sat_walk_kernel<1, 2>", "sat_walk_kernel", 2, 64),
+    for inst, kernel, dbl, fpl in (("sat_walk_kernel<1, 2>", "sat_walk_kernel", 2, 32),
                                    ("sample_rect_stream_batch_kernel<3>", "sample_rect_kernel", 2, 16),
                                    ("sat_write_kernel<1, 1>", "sat_write_kernel", 2, 1),
                                    ("sat_reduce_kernel<1>", "sat_reduce_kernel", 2, 1),
@@ -79,7 +79,7 @@ def main():
     if len(sys.argv) >= 6:
         yf, yw = means(sys.argv[4], "FETCH_SIZE"), means(sys.argv[5], "WRITE_SIZE")
         # planar source, x86 rounding model = 3
-        for inst, kernel, fpl in (("sat_walk_kernel<3, 2>", "sat_walk_kernel", 64),
+        for inst, kernel, fpl in (("sat_walk_kernel<3, 2>", "sat_walk_kernel", 32),
                                   ("sat_write_kernel<3, 1>", "sat_write_kernel", 1),
                                   ("sat_reduce_kernel<3>", "sat_reduce_kernel", 1)):
             if inst in yf and inst in yw:
