@@ -61,7 +61,7 @@ def functions(path):
             base, cur = int(m.group(1), 16), m.group(2)
             funcs[cur] = []
             continue
-        m = re.match(r"^\t(.+?)\s+// ([0-9A-F]{12}):", line)
+        m = re.match(r"^\t(.+?)\s*// ([0-9A-F]{12}):", line)
         if not (m and cur):
             continue
         text, addr = m.group(1).strip(), int(m.group(2), 16)
@@ -133,10 +133,11 @@ def main():
                     if any(t.startswith(("scratch_", "s_swappc")) for t in texts):
                         perf.append(f"{name}: scratch memory or a call in the strip walker")
                     # (the debug statistics behind the last table store are plain stores)
+                    # (the debug statistics are the only other 16-byte stores: scalar base, plain)
                     nts = [i for i, t in enumerate(texts)
                            if t.startswith("global_store_dwordx4") and " nt" in t]
-                    if len(nts) < 24 or any(t.startswith("global_store_dwordx4") and " nt" not in t
-                                            for t in texts[nts[0]:nts[-1] + 1]):
+                    if len(nts) < 24 or any(t.startswith("global_store_dwordx4") and ", off" in t
+                                            and " nt" not in t for t in texts):
                         perf.append(f"{name}: a table store lost its nt bit")
                     gran = [t for t in texts if t.startswith("global_store_dwordx2")]
                     if not gran or any(" sc1" not in t for t in gran):
