@@ -235,6 +235,11 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
         ls = w * bpp
         rw, rh = reduced(w), reduced(h)
         gpu_ctx.set_option("sample.variant", int(rng.choice([1, 2, 2])))
+        # the read-once strip walker whenever the layout allows it (every other case), with
+        # random depth and frames per launch; else the automatic choice (three kernels here)
+        gpu_ctx.set_option("sat.walk", 1 if case % 2 else -1)
+        gpu_ctx.set_option("sat.walk_depth", int(rng.choice([2, 3])))
+        gpu_ctx.set_option("sat.walk_frames", int(rng.choice([0, 1, 3, 7, 64])))
         frames = [rng.integers(0, 256, (h, ls), dtype=np.uint8) for _ in range(n)]
         gazes = [random_gaze(rng) for _ in range(n)]
         srcs = [gpu_ctx.upload(f) for f in frames]
@@ -258,6 +263,9 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
             b.free()
         dec.close()
     gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
+    gpu_ctx.set_option("sat.walk", -1)
+    gpu_ctx.set_option("sat.walk_depth", 2)
+    gpu_ctx.set_option("sat.walk_frames", 0)
 
 
 def test_random_output_colour_step(f360, gpu_ctx, oracle):
