@@ -159,6 +159,7 @@ struct f360_ctx {
   int opt_walk_depth = 2;      // "sat.walk_depth": 8-row batches a strip owner rotates through (2 | 3), all but one in flight
   int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
+  int opt_interp_staged = 1;   // "interp.staged": the un-warp computes the vertical lerps once per reduced column (wave-private LDS) instead of per output pixel
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer

@@ -277,6 +277,7 @@ static const OptionSlot kOptions[] = {
     {"sat.walk_frames", &f360_ctx::opt_walk_frames},
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"interp.rows", &f360_ctx::opt_interp_rows},
+    {"interp.staged", &f360_ctx::opt_interp_staged},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
     {"yuv.model", &f360_ctx::opt_yuv_model},
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},

@@ -612,11 +612,40 @@ __device__ __forceinline__ InterpAxis interp_axis(int pos, int centre, int4 entr
 constexpr int kInterpCols = 4;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// STAGED ("interp.staged", the default): away from the fovea up to 23 adjacent output columns
+// lie between the same two reduced columns, and the vertical lerps of the kernel text (:143-146:
+// mix(top, bottom, y_ratio) for the left and for the right neighbour) depend on the reduced
+// column only -- so the wave computes them ONCE per reduced column of its span (at most
+// kInterpSpan x 64 of them, loaded as coalesced rows instead of four gathers per pixel), parks
+// them in wave-private LDS as float3, and an output pixel is two 16-byte LDS reads and the
+// horizontal lerp.  The arithmetic per value is the kernel text's, operation for operation
+// (unfused, same order), so the bytes are unchanged; a wave whose columns straddle the wrap seam
+// (reduced columns from both ends of the row) keeps the per-pixel gathers.
+constexpr int kInterpSpan = 5;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void interp_lds_write(uint32_t addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// eight 16-byte reads (left / right vertical lerps of a lane's four pixels), one wait
+__device__ __forceinline__ void interp_lds_read8(const uint32_t (&a)[4], const uint32_t (&b)[4],
+                                                 f32x4 (&l)[4], f32x4 (&r)[4]) {
+  asm volatile(
+      "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\t"
+      "ds_read_b128 %3, %11\n\tds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\t"
+      "ds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3]), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]),
+        "=&v"(r[3])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3])
+      : "memory");
+}
+
+template <bool STAGED>
 __global__ __launch_bounds__(256) void interpolate_rect_kernel(
     uint32_t *__restrict__ dst, int out_w, int out_h,
     const uint32_t *__restrict__ src, int src_w, int src_h,
     const int4 *__restrict__ tx, int range_x, const int4 *__restrict__ ty,
     int range_y, int cxp, int cyp, int rows) {
+  __shared__ __attribute__((aligned(16))) float lerp_stage[STAGED ? 4 * kInterpSpan * 64 * 4 : 4];
   const int lane = threadIdx.x & 63;
   const int x_base = ((int)blockIdx.x * 64 + lane) * kInterpCols;
   const int y0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * rows);
@@ -669,6 +698,170 @@ __global__ __launch_bounds__(256) void interpolate_rect_kernel(
   int held_lo = -1, held_hi = -1;  // reduced rows the registers above hold
 
   const int y1 = min(y0 + rows, out_h);
+  if constexpr (STAGED) {
+    // the wave's span of reduced columns
+    int c_lo = ax[0].lo, c_hi = ax[0].hi;
+#pragma unroll
+    for (int k = 1; k < kInterpCols; ++k) {
+      c_lo = min(c_lo, ax[k].lo);
+      c_hi = max(c_hi, ax[k].hi);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      c_lo = min(c_lo, __shfl_xor(c_lo, m, 64));
+      c_hi = max(c_hi, __shfl_xor(c_hi, m, 64));
+    }
+    const int cmin = __builtin_amdgcn_readfirstlane(c_lo);
+    const int cmax = __builtin_amdgcn_readfirstlane(c_hi);
+    if (cmax - cmin < kInterpSpan * 64) {
+      const int ngroups = (cmax - cmin) / 64 + 1;  // 64-column groups the wave stages
+      const uint32_t mine = (uint32_t)reinterpret_cast<uintptr_t>(lerp_stage) +
+                            (uint32_t)(threadIdx.x >> 6) * (kInterpSpan * 64 * 16);
+      uint32_t at_lo[kInterpCols], at_hi[kInterpCols];
+#pragma unroll
+      for (int k = 0; k < kInterpCols; ++k) {
+        at_lo[k] = mine + (uint32_t)(ax[k].lo - cmin) * 16u;
+        at_hi[k] = mine + (uint32_t)(ax[k].hi - cmin) * 16u;
+      }
+      // Away from the fovea the span is one or two groups: then the texels of ALL the wave's rows
+      // are requested before the first is used (a row pair that repeats is a cache hit), so the
+      // wave pays one memory round trip instead of one per distinct pair of reduced rows.
+      constexpr int kPre = 8;  // rows whose texels are requested together
+      if (ngroups <= 2) {
+       for (int yc = y0; yc < y1; yc += kPre) {  // chunks of kPre rows
+        uint32_t ptop[kPre][2], pbot[kPre][2];
+#pragma unroll
+        for (int r = 0; r < kPre; ++r) {
+          const int y = min(yc + r, y1 - 1);
+          const InterpAxis ay = interp_axis(y, cyp, ty[y - cyp + range_y], false, out_h, src_h, src_h);
+          const uint32_t r_lo = (uint32_t)ay.lo * row_bytes, r_hi = (uint32_t)ay.hi * row_bytes;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t c = (uint32_t)min(cmin + lane + 64 * j, cmax) * 4u;
+            ptop[r][j] = texel(r_lo + c);
+            pbot[r][j] = texel(r_hi + c);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kPre; ++r) {
+          const int y = yc + r;
+          if (y >= y1) break;
+          const InterpAxis ay = interp_axis(y, cyp, ty[y - cyp + range_y], false, out_h, src_h, src_h);
+          uint32_t out[kInterpCols];
+          const float yr = ay.ratio;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (j >= ngroups) break;  // wave-uniform
+            f32x4 v;
+            v.w = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float ft = (float)((ptop[r][j] >> (8 * c)) & 0xffu);
+              const float fb = (float)((pbot[r][j] >> (8 * c)) & 0xffu);
+              const float lerp = ft + (fb - ft) * yr;
+              if (c == 0) v.x = lerp;
+              if (c == 1) v.y = lerp;
+              if (c == 2) v.z = lerp;
+            }
+            interp_lds_write(mine + (uint32_t)(lane + 64 * j) * 16u, v);
+          }
+          f32x4 l[kInterpCols], rr[kInterpCols];
+          interp_lds_read8(at_lo, at_hi, l, rr);
+#pragma unroll
+          for (int k = 0; k < kInterpCols; ++k) {
+            const float xr = ax[k].ratio;
+            const float m0 = l[k].x + (rr[k].x - l[k].x) * xr;
+            const float m1 = l[k].y + (rr[k].y - l[k].y) * xr;
+            const float m2 = l[k].z + (rr[k].z - l[k].z) * xr;
+            out[k] = ((uint32_t)(int)m0 & 0xffu) | (((uint32_t)(int)m1 & 0xffu) << 8) |
+                     (((uint32_t)(int)m2 & 0xffu) << 16);
+          }
+          if (ay.exact) {  // wave-uniform: rows that hit a reduced row exactly
+#pragma unroll
+            for (int k = 0; k < kInterpCols; ++k)
+              if (ax[k].exact)  // exact hit on both axes -> plain copy
+                out[k] = texel((uint32_t)ay.exact_idx * row_bytes + off_ex[k]) & 0x00ffffffu;
+          }
+          uint32_t *o = dst + (size_t)y * out_w + x_base;
+          if (vec_store && x_base < out_w) {
+            F360_STREAM_STORE(reinterpret_cast<u32x4_t *>(o),
+                              (u32x4_t{out[0], out[1], out[2], out[3]}));
+          } else {
+#pragma unroll
+            for (int k = 0; k < kInterpCols; ++k)
+              if (x_base + k < out_w) o[k] = out[k];
+          }
+        }
+       }
+        return;
+      }
+      uint32_t top[kInterpSpan], bot[kInterpSpan];
+      int row_lo = -1, row_hi = -1;
+      for (int y = y0; y < y1; ++y) {
+        const InterpAxis ay = interp_axis(y, cyp, ty[y - cyp + range_y], false, out_h, src_h, src_h);
+        uint32_t out[kInterpCols];
+        if (ay.exact && wave_exact_x) {  // :67-72 for the whole wave: plain copies
+#pragma unroll
+          for (int k = 0; k < kInterpCols; ++k)
+            out[k] = texel((uint32_t)ay.exact_idx * row_bytes + off_ex[k]) & 0x00ffffffu;
+        } else {
+          if (ay.lo != row_lo || ay.hi != row_hi) {  // wave-uniform: the two reduced rows
+            const uint32_t r_lo = (uint32_t)ay.lo * row_bytes, r_hi = (uint32_t)ay.hi * row_bytes;
+#pragma unroll
+            for (int j = 0; j < kInterpSpan; ++j) {
+              const uint32_t c = (uint32_t)min(cmin + lane + 64 * j, cmax) * 4u;
+              top[j] = texel(r_lo + c);
+              bot[j] = texel(r_hi + c);
+            }
+            row_lo = ay.lo;
+            row_hi = ay.hi;
+          }
+          const float yr = ay.ratio;
+#pragma unroll
+          for (int j = 0; j < kInterpSpan; ++j) {
+            if (j >= ngroups) break;  // wave-uniform
+            f32x4 v;
+            v.w = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float ft = (float)((top[j] >> (8 * c)) & 0xffu);
+              const float fb = (float)((bot[j] >> (8 * c)) & 0xffu);
+              const float lerp = ft + (fb - ft) * yr;
+              if (c == 0) v.x = lerp;
+              if (c == 1) v.y = lerp;
+              if (c == 2) v.z = lerp;
+            }
+            interp_lds_write(mine + (uint32_t)(lane + 64 * j) * 16u, v);
+          }
+          f32x4 l[kInterpCols], r[kInterpCols];
+          interp_lds_read8(at_lo, at_hi, l, r);
+#pragma unroll
+          for (int k = 0; k < kInterpCols; ++k) {
+            const float xr = ax[k].ratio;
+            const float m0 = l[k].x + (r[k].x - l[k].x) * xr;
+            const float m1 = l[k].y + (r[k].y - l[k].y) * xr;
+            const float m2 = l[k].z + (r[k].z - l[k].z) * xr;
+            out[k] = ((uint32_t)(int)m0 & 0xffu) | (((uint32_t)(int)m1 & 0xffu) << 8) |
+                     (((uint32_t)(int)m2 & 0xffu) << 16);
+          }
+#pragma unroll
+          for (int k = 0; k < kInterpCols; ++k)
+            if (ay.exact && ax[k].exact)  // exact hit on both axes -> plain copy
+              out[k] = texel((uint32_t)ay.exact_idx * row_bytes + off_ex[k]) & 0x00ffffffu;
+        }
+        uint32_t *o = dst + (size_t)y * out_w + x_base;
+        if (vec_store && x_base < out_w) {
+          F360_STREAM_STORE(reinterpret_cast<u32x4_t *>(o),
+                            (u32x4_t{out[0], out[1], out[2], out[3]}));
+        } else {
+#pragma unroll
+          for (int k = 0; k < kInterpCols; ++k)
+            if (x_base + k < out_w) o[k] = out[k];
+        }
+      }
+      return;
+    }
+  }
   for (int y = y0; y < y1; ++y) {
     const InterpAxis ay = interp_axis(y, cyp, ty[y - cyp + range_y], false, out_h, src_h, src_h);
     uint32_t out[kInterpCols];
@@ -1274,11 +1467,18 @@ int f360_satdec_interpolate_rect(f360_sat_decoder *dec, uint8_t *target_dev,
                   (target_height + 4 * rows - 1) / (4 * rows));
   f360::KernelSpan span(dec->ctx, f360::kInterpolateRect,
                         f360::take_profile_slot(dec->ctx));
-  hipLaunchKernelGGL(interpolate_rect_kernel, grid, dim3(256), 0, dec->ctx->stream,
-                     reinterpret_cast<uint32_t *>(target_dev), target_width,
-                     target_height, reinterpret_cast<const uint32_t *>(source_dev),
-                     source_width, source_height, dec->itx_dev.as<int4>(),
-                     dec->it_dx, dec->ity_dev.as<int4>(), dec->it_dy, cxp, cyp, rows);
+  if (dec->ctx->opt_interp_staged)
+    hipLaunchKernelGGL(interpolate_rect_kernel<true>, grid, dim3(256), 0, dec->ctx->stream,
+                       reinterpret_cast<uint32_t *>(target_dev), target_width,
+                       target_height, reinterpret_cast<const uint32_t *>(source_dev),
+                       source_width, source_height, dec->itx_dev.as<int4>(),
+                       dec->it_dx, dec->ity_dev.as<int4>(), dec->it_dy, cxp, cyp, rows);
+  else
+    hipLaunchKernelGGL(interpolate_rect_kernel<false>, grid, dim3(256), 0, dec->ctx->stream,
+                       reinterpret_cast<uint32_t *>(target_dev), target_width,
+                       target_height, reinterpret_cast<const uint32_t *>(source_dev),
+                       source_width, source_height, dec->itx_dev.as<int4>(),
+                       dec->it_dx, dec->ity_dev.as<int4>(), dec->it_dy, cxp, cyp, rows);
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }
