@@ -291,8 +291,8 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
   for (const OptionSlot &s : kOptions)
     if (std::strcmp(s.key, key) == 0) {
       if (s.field == &f360_ctx::opt_band_rows)
-        F360_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64,
-                     "sat.band_rows must be 0 (automatic), 16, 32 or 64 (got %d)", value);
+        F360_REQUIRE(value == 0 || value == 8 || value == 16 || value == 32 || value == 64,
+                     "sat.band_rows must be 0 (automatic), 8, 16, 32 or 64 (got %d)", value);
       if (s.field == &f360_ctx::opt_sb_bands)
         F360_REQUIRE(value >= -1 && value <= 64, "sat.sb_bands out of range: %d",
                      value);

@@ -602,6 +602,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
                   xm[3] == xm[0] + 3 && xm_first >= 0);
   }
 
+  const int y_end = min((band + 1) * a.band_rows, a.height);
+  const uint32_t *rc = a.rowcarry + fr.ws + (size_t)strip * a.height * 3;
+  // A batch = kRowUnroll rows of pixels plus their row carries (3 dwords per row, fetched by
+  // lanes 0..23 in one load and broadcast with v_readlane: a per-row load of a wave-uniform
+  // address would be one more vector-memory operation to wait for in every row).  No branch
+  // around any load (addresses are clamped to the band's last row): see sat_reduce_kernel.
+  auto load_batch = [&](RowBatch<SRC> &raw, uint32_t &carry, int y) {
+    if constexpr (SRC == kSrcBytes) {
+#pragma unroll
+      for (int r = 0; r < kRowUnroll; ++r)
+        raw.raw[r] = (y + r < y_end)
+                         ? load_px4<SRC>(fr.src, a.width, y + r, x0, a.linesize, a.bpp)
+                         : make_uint4(0, 0, 0, 0);
+    } else {
+      reduce_load_batch<SRC>(a, fr, raw, y, x0, y_end - 1);
+    }
+    const uint32_t *cp = rc + min(y * 3 + min(lane, 3 * kRowUnroll - 1), a.height * 3 - 1);
+    if (STORE == 2 && lane >= 32)  // emit mode: lanes 32..39 fetch the rows' compact indices
+      cp = reinterpret_cast<const uint32_t *>(a.ymap) +
+           min(y + min(lane - 32, kRowUnroll - 1), a.height - 1);
+    carry = *cp;
+  };
+  // The band's first two batches of pixels are requested BEFORE the prologue's own loads (the
+  // carried-in column sums, the corner look-back): those used to be three memory round trips in
+  // a row before the first pixel load was even issued; now everything is in flight together.
+  RowBatch<SRC> buf_a, buf_b;
+  uint32_t carry_a, carry_b;
+  const int y_begin = band * a.band_rows;
+  load_batch(buf_a, carry_a, y_begin);
+  load_batch(buf_b, carry_b, y_begin + kRowUnroll);
+
   // --- table row just above the band, for this lane's 4 pixels -------------
   uint32_t acc[12];
   {
@@ -639,28 +670,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
     acc[9 + c] += excl;
   }
 
-  const int y_end = min((band + 1) * a.band_rows, a.height);
-  const uint32_t *rc = a.rowcarry + fr.ws + (size_t)strip * a.height * 3;
-  // A batch = kRowUnroll rows of pixels plus their row carries (3 dwords per row, fetched by
-  // lanes 0..23 in one load and broadcast with v_readlane: a per-row load of a wave-uniform
-  // address would be one more vector-memory operation to wait for in every row).  No branch
-  // around any load (addresses are clamped to the band's last row): see sat_reduce_kernel.
-  auto load_batch = [&](RowBatch<SRC> &raw, uint32_t &carry, int y) {
-    if constexpr (SRC == kSrcBytes) {
-#pragma unroll
-      for (int r = 0; r < kRowUnroll; ++r)
-        raw.raw[r] = (y + r < y_end)
-                         ? load_px4<SRC>(fr.src, a.width, y + r, x0, a.linesize, a.bpp)
-                         : make_uint4(0, 0, 0, 0);
-    } else {
-      reduce_load_batch<SRC>(a, fr, raw, y, x0, y_end - 1);
-    }
-    const uint32_t *cp = rc + min(y * 3 + min(lane, 3 * kRowUnroll - 1), a.height * 3 - 1);
-    if (STORE == 2 && lane >= 32)  // emit mode: lanes 32..39 fetch the rows' compact indices
-      cp = reinterpret_cast<const uint32_t *>(a.ymap) +
-           min(y + min(lane - 32, kRowUnroll - 1), a.height - 1);
-    carry = *cp;
-  };
   auto write_batch = [&](const RowBatch<SRC> &raw, uint32_t carry, int y) {
 #pragma unroll
     for (int r = 0; r < kRowUnroll; ++r) {
@@ -757,15 +766,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   };
   // two batches alternate (a band is 2, 4 or 8 batches): the next one is in flight while this
   // one is scanned and stored
-  RowBatch<SRC> buf_a, buf_b;
-  uint32_t carry_a, carry_b;
-  const int y_begin = band * a.band_rows;
-  load_batch(buf_a, carry_a, y_begin);
   for (int y = y_begin; y < y_end; y += 2 * kRowUnroll) {
-    load_batch(buf_b, carry_b, y + kRowUnroll);
     write_batch(buf_a, carry_a, y);
     load_batch(buf_a, carry_a, y + 2 * kRowUnroll);
     if (y + kRowUnroll < y_end) write_batch(buf_b, carry_b, y + kRowUnroll);
+    load_batch(buf_b, carry_b, y + 3 * kRowUnroll);
   }
 }
 

@@ -88,7 +88,8 @@ def test_sat_encode_matches_oracle(f360, gpu_ctx, oracle, w, h, bpp, pad, off):
 
 
 @pytest.mark.parametrize("band_rows,sb_bands,store", [(16, 8, 0), (32, 8, 1), (64, 4, 0),
-                                                      (32, 1, 0), (16, 64, 1), (32, 3, 1)])
+                                                      (32, 1, 0), (16, 64, 1), (32, 3, 1),
+                                                      (8, 1, 1), (8, 2, 0), (8, 5, 1)])
 def test_sat_encode_tiling_options(f360, gpu_ctx, oracle, band_rows, sb_bands, store):
     w, h = 1336, 203  # neither a multiple of the strip nor of any band height
     frame = oracle.lcg_frame(w, h, 77)

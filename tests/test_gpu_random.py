@@ -51,7 +51,7 @@ def test_random_sat_encode(f360, gpu_ctx, oracle):
             ls = w * bpp + pad
             if ls // w != bpp:   # keep the reference's bytes-per-pixel = linesize / width
                 ls = w * bpp
-            gpu_ctx.set_option("sat.band_rows", int(rng.choice([0, 16, 32, 64])))
+            gpu_ctx.set_option("sat.band_rows", int(rng.choice([0, 8, 16, 32, 64])))
             gpu_ctx.set_option("sat.sb_bands", int(rng.choice([0, 1, 2, 3, 8])))
             gpu_ctx.set_option("sat.store", int(rng.integers(0, 2)))
             frame = rng.integers(0, 256, (h, ls), dtype=np.uint8)
@@ -178,7 +178,7 @@ def test_random_planar_sources(f360, gpu_ctx, oracle):
             w, h = max(4, w // 4 * 4), max(2, h // 2 * 2)
             model = int(rng.integers(0, 2))
             gpu_ctx.set_option("yuv.model", model)
-            gpu_ctx.set_option("sat.band_rows", int(rng.choice([0, 16, 32, 64])))
+            gpu_ctx.set_option("sat.band_rows", int(rng.choice([0, 8, 16, 32, 64])))
             gpu_ctx.set_option("sat.sb_bands", int(rng.choice([-1, 0, 1, 2, 3])))
             ypad, cpad = int(rng.choice([0, 4, 8])), int(rng.choice([0, 2, 6]))
             y = rng.integers(0, 256, (h, w + ypad), dtype=np.uint8)
