@@ -156,6 +156,7 @@ struct f360_ctx {
   int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows
   int opt_walk_units = 960;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder
   int opt_walk_frames = 0;     // "sat.walk_frames": most frames one read-once launch takes (1..64); 0 = about 1024 strip owners, one per SIMD
+  int opt_walk_variant = 1;    // "sat.walk_variant": read-once kernel for RGB0 frames: 1 sat_walk_kernel, 2 sat_walk2_kernel (LDS-DMA pixels and polls, exact wait counts: no per-batch store drain)
   int opt_walk_depth = 2;      // "sat.walk_depth": 8-row batches a strip owner rotates through (2 | 3), all but one in flight
   int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up

@@ -274,6 +274,7 @@ static const OptionSlot kOptions[] = {
     {"sat.walk", &f360_ctx::opt_walk},
     {"sat.walk_units", &f360_ctx::opt_walk_units},
     {"sat.walk_depth", &f360_ctx::opt_walk_depth},
+    {"sat.walk_variant", &f360_ctx::opt_walk_variant},
     {"sat.walk_frames", &f360_ctx::opt_walk_frames},
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"interp.rows", &f360_ctx::opt_interp_rows},
@@ -310,6 +311,8 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
         F360_REQUIRE(value >= -1 && value <= 1, "sat.walk must be -1 (automatic), 0 or 1: %d", value);
       if (s.field == &f360_ctx::opt_walk_depth)
         F360_REQUIRE(value >= 2 && value <= 3, "sat.walk_depth must be 2 or 3: %d", value);
+      if (s.field == &f360_ctx::opt_walk_variant)
+        F360_REQUIRE(value == 1 || value == 2, "sat.walk_variant must be 1 or 2: %d", value);
       if (s.field == &f360_ctx::opt_walk_frames)
         F360_REQUIRE(value >= 0 && value <= 64, "sat.walk_frames out of range 0..64: %d", value);
       if (s.field == &f360_ctx::opt_walk_units)

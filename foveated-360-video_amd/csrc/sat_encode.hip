@@ -917,6 +917,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
     for (int e = 0; e < 12; ++e) acc[e] = 0;
     uint32_t slow_polls = 0, spun = 0;  // hand-off waits that took the slow path, their polls
     const unsigned long long t_start = (a.ablate & 256) ? __builtin_amdgcn_s_memrealtime() : 0;
+    const unsigned long long c_start = (a.ablate & 256) ? __builtin_amdgcn_s_memtime() : 0;
 
     auto walk_batch = [&](const RowBatch<SRC> &raw, unsigned long long g, int t) {
       const int y = t * kRowUnroll;
@@ -1029,7 +1030,9 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
       // bit the ISA guard checks)
       ulonglong2 *st = reinterpret_cast<ulonglong2 *>(a.walk_stats + (size_t)unit * 4);
       st[0] = make_ulonglong2(t_start, __builtin_amdgcn_s_memrealtime());
-      st[1] = make_ulonglong2(slow_polls, spun);
+      // (slow waits in 16 bits, above them the shader-clock cycles of the walk: boxes differ)
+      st[1] = make_ulonglong2(
+          slow_polls | ((__builtin_amdgcn_s_memtime() - c_start) << 16), spun);
     }
   }
   // retire: the last wave of the launch re-arms the state for the next one
@@ -1046,6 +1049,8 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
     }
   }
 }
+
+#include "sat_walk_nodrain.h"
 
 int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false, int frames = 1) {
   f360::SatEncodePlan &p = ctx->enc;
@@ -1410,6 +1415,9 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
       F360_WALK_LAUNCH(kSrcYuvSwsX86);
     else if (yuv_src == kSrcYuvSwsC)
       F360_WALK_LAUNCH(kSrcYuvSwsC);
+    else if (ctx->opt_walk_variant == 2)  // no per-batch store drain (sat_walk_nodrain.h)
+      hipLaunchKernelGGL(sat_walk2_kernel, dim3((a.walk_units + kW2Waves - 1) / kW2Waves),
+                         dim3(64 * kW2Waves), 0, ctx->stream, a, wb);
     else
       F360_WALK_LAUNCH(kSrcRgb0);
 #undef F360_WALK_LAUNCH
@@ -1421,7 +1429,7 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
 }  // namespace
 
 // Debug: the per-unit statistics of the last read-once launch that ran with debug.ablate bit 8
-// ({start, end} in 100 MHz ticks, slow-path waits, polls spent in them); returns the unit count.
+// ({start, end} in 100 MHz ticks, slow-path waits | shader cycles << 16, polls spent waiting); returns the unit count.
 extern "C" int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int max_units) {
   F360_REQUIRE(ctx && out && max_units >= 0, "f360_debug_walk_stats: bad argument");
   F360_BIND_DEVICE(ctx);

@@ -158,6 +158,21 @@ def main():
                                         f"of the row loop")
                         if not any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in body):
                             perf.append(f"{name}: the row loop has no counted vmcnt wait")
+                # the variant without store drains (sat.walk_variant = 2): its hand-off poll is an
+                # LDS-direct load and must carry sc1 like the register polls; same granule rule
+                if "sat_walk2_kernel" in name:
+                    seen.add("walker (no-drain variant)")
+                    if any(t.startswith(("scratch_", "s_swappc")) for t in texts):
+                        perf.append(f"{name}: scratch memory or a call in the strip walker")
+                    gran = [t for t in texts if t.startswith("global_store_dwordx2")]
+                    if not gran or any(" sc1" not in t for t in gran):
+                        errors.append(f"{name}: hand-off granule stores must be sc1 (write-through)")
+                    dma = [t for t in texts if t.startswith("global_load_lds_dwordx4")]
+                    if not any(" sc1" in t for t in dma):
+                        errors.append(f"{name}: the LDS-direct hand-off poll must be sc1")
+                    if any(t.startswith("global_store_dwordx4") and ", off" in t and " nt" not in t
+                           for t in texts):
+                        perf.append(f"{name}: a table store lost its nt bit")
                 # hipcc 7.2 miscompiles byte packing around this instruction (its upper half is
                 # not zero on gfx950 but later ORs assume so): both times it appeared, the parity
                 # tests failed; the kernels are written so that it is not selected

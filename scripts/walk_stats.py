@@ -37,7 +37,13 @@ def main():
     for _ in range(2):
         enc.EncodeFramesGPU([s.data_ptr() for s in sats], [frames[k].data_ptr() for k in range(n)], w, h, 4 * w)
     torch.cuda.synchronize()
-    st = ctx.debug_walk_stats(n * 64).astype(np.float64)
+    raw = ctx.debug_walk_stats(n * 64)
+    cycles = (raw[:, 2] >> np.uint64(16)).astype(np.float64)
+    raw[:, 2] &= np.uint64(0xffff)
+    st = raw.astype(np.float64)
+    ticks = st[:, 1] - st[:, 0]
+    ok = (ticks > 0) & (cycles > 0)
+    mhz = float(np.median(cycles[ok] / ticks[ok] * 100.0)) if ok.any() else None
     nstrips = (w + 255) // 256
     st = st[: n * nstrips].reshape(n, nstrips, 4)
     t0 = st[:, :, 0].min()
@@ -50,7 +56,7 @@ def main():
            "busy_us_by_strip_mean": [round(float(x), 1) for x in (end - start).mean(axis=0)],
            "slow_waits_by_strip_mean": [round(float(x), 1) for x in st[:, :, 2].mean(axis=0)],
            "polls_by_strip_mean": [round(float(x), 1) for x in st[:, :, 3].mean(axis=0)],
-           "batches_per_strip": (h + 7) // 8}
+           "batches_per_strip": (h + 7) // 8, "shader_mhz_median": mhz}
     print(json.dumps(out))
 
 
