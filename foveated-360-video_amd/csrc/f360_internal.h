@@ -164,6 +164,7 @@ struct f360_ctx {
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
+  int opt_lp_lds = 1;          // "is.lp_lds": log-polar un-warp keeps its axis tables in LDS (needs is.lp_table); 0 off, 1 on, 256 / 512 / 1024 = on with that workgroup size
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos), 2 two planes (sin, cos)
   int opt_gnomonic_fast = 0;   // "gnomonic.fast": asin / atan2 through cr_math.h (cheap double evaluation + rounding guard, library routine for the rejected lanes)
@@ -286,4 +287,6 @@ struct f360_image_sampler {
   // interpolate_logpolar: offset -> reduced-buffer coordinate table of one geometry
   int lpt_w = 0, lpt_h = 0, lpt_sw = 0, lpt_sh = 0;
   f360::DevBuf lpt_dev;
+  bool lp_lds_ready = false;  // LDS-table un-warp: kernel attribute set, CU count known
+  int lp_cus = 0;
 };

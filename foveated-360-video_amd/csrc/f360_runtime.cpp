@@ -285,6 +285,7 @@ static const OptionSlot kOptions[] = {
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"gnomonic.fast", &f360_ctx::opt_gnomonic_fast},
     {"is.lp_table", &f360_ctx::opt_lp_table},
+    {"is.lp_lds", &f360_ctx::opt_lp_lds},
 };
 
 int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
@@ -319,6 +320,10 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
         F360_REQUIRE(value >= 1, "sat.walk_units must be >= 1: %d", value);
       if (s.field == &f360_ctx::opt_sample_fpl)
         F360_REQUIRE(value >= 1 && value <= 64, "sample.fpl out of range 1..64: %d", value);
+      if (s.field == &f360_ctx::opt_lp_lds)
+        F360_REQUIRE(value == 0 || value == 1 || value == 256 || value == 512 || value == 1024,
+                     "is.lp_lds must be 0 (off), 1 (on) or a workgroup size 256 / 512 / 1024: %d",
+                     value);
       if (s.field == &f360_ctx::opt_sample_variant)
         F360_REQUIRE(value >= 0 && value <= 2, "sample.variant must be 0, 1 or 2: %d", value);
       ctx->*(s.field) = value;

@@ -21,6 +21,11 @@ __device__ __forceinline__ float cr_atanf(float x) { return (float)atan((double)
 __device__ __forceinline__ float mixf(float a, float b, float t) {
   return a + (b - a) * t;
 }
+typedef float f32x2_is __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(4))) uint2_a4 {  // an 8-byte load from a 4-byte aligned address
+  uint32_t x, y;
+  __device__ operator uint2() const { return make_uint2(x, y); }
+};
 
 // host side: may a launch use 4-byte accesses?
 inline bool word_pixels(const void *dst, int dst_linesize, int dst_w, const void *src,
@@ -269,6 +274,151 @@ __global__ __launch_bounds__(256) void is_interpolate_logpolar_kernel(
       }
     }
     dst[(size_t)(y0 + k) * out_w + x0] = out;
+  }
+}
+
+// The same kernel for the common case -- the whole frame inside the offset table, the three axis
+// tables small enough for LDS -- restructured around what bounded the kernel above (1109
+// instructions for four pixels, 33 branches, 22 waits; 7 scattered requests per pixel):
+//   * the radius / cos / sin tables of the exact-hit test (:47-52) sit in LDS (17 + 34 KB at 8K),
+//     loaded once by a workgroup that then loops over tiles: three global gathers per pixel
+//     become one 4-byte and one 16-byte LDS read;
+//   * the four texels are two 8-byte loads: ceil(i) is floor(i) or floor(i) + 1, so the left and
+//     right neighbour are adjacent in their row (the pair starts at min(min_i, width - 2));
+//   * the exact-hit texel (j, i) is one of those four unless float rounding in `j_float +
+//     source_height` or the clamp of j at the last row says otherwise: a wave-uniform, almost
+//     never taken branch fetches it then;
+//   * no branch on the main path (floor / ceil / round share one v_floor; the `%` of :59-61 is two
+//     conditional subtractions: its argument lies in [n, 2n + 1]), so the compiler issues the
+//     loads of a thread's four rows together: three round trips per four pixels;
+//   * the lerps run two values per packed-float instruction, same operations in the same order.
+// i_float and j_float are never negative (log of a radius >= 1; fmod of a positive number; a
+// positive constant), which round() as floor + (fraction >= 0.5) relies on.
+constexpr uint32_t kLpLdsMax = 96 * 1024;
+
+__device__ __forceinline__ f32x2_is lerp2(f32x2_is a, f32x2_is b, float t) {
+  return a + (b - a) * t;  // -ffp-contract=off: sub, mul, add like mix()
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void is_interpolate_logpolar_lds_kernel(
+    uint32_t *__restrict__ dst, int out_w, int out_h, const uint32_t *__restrict__ src, int src_w,
+    int src_h, const float *__restrict__ rad, const double *__restrict__ cs,
+    const double *__restrict__ sn, float cxf, float cyf, int cxp, int cyp,
+    const LogpolarTable table, int tiles_x, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
+  double2 *l_cs = reinterpret_cast<double2 *>(lp_lds);           // [src_h] {cos, sin}
+  float *l_rad = reinterpret_cast<float *>(l_cs + src_h);        // [src_w]
+  for (int i = threadIdx.x; i < src_h; i += THREADS) l_cs[i] = make_double2(cs[i], sn[i]);
+  for (int i = threadIdx.x; i < src_w; i += THREADS) l_rad[i] = rad[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rw = src_w, rh = src_h;
+  const double cxd = (double)cxf, cyd = (double)cyf;
+  const float hf = (float)src_h;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x0 = tx * 64 + lane;
+    const int y0 = (ty * (THREADS / 64) + wave) * kLpRows;
+    if (x0 >= out_w || y0 >= out_h) continue;
+    int x = x0;
+    if (x - cxp > out_w / 2)
+      x -= out_w;
+    else if (x - cxp < (-out_w) / 2)
+      x += out_w;
+    const int dx = x - cxp;
+    const uint32_t col = (uint32_t)min(max(dx + table.span_x, 0), 2 * table.span_x);
+
+    float2 uv[kLpRows];
+#pragma unroll
+    for (int k = 0; k < kLpRows; ++k) {
+      const int dy = min(y0 + k, out_h - 1) - cyp;
+      const uint32_t row = (uint32_t)min(max(dy + table.span_y, 0), 2 * table.span_y);
+      // (24-bit multiplies are full rate, 32-bit ones quarter rate: rows, pitches and widths
+      // are below 2^17 + 4, the products below 2^29 -- host check)
+      uv[k] = table.uv[__umul24(row, (uint32_t)table.pitch) + col];
+    }
+    int ii[kLpRows], jj[kLpRows], min_i[kLpRows], max_i[kLpRows], min_j[kLpRows], max_j[kLpRows];
+    float ir[kLpRows], jr[kLpRows];
+    bool exact[kLpRows];
+    uint2 top[kLpRows], bot[kLpRows];
+    int base_i[kLpRows];
+#pragma unroll
+    for (int k = 0; k < kLpRows; ++k) {
+      const float i_f = uv[k].x, j_f = uv[k].y;
+      const float fi = floorf(i_f), fj = floorf(j_f);
+      ir[k] = i_f - fi;
+      jr[k] = j_f - fj;
+      const int i0 = (int)fi, j0 = (int)fj;
+      // (unsigned min: the lower clamp of :34,44,57,59 cannot act on a non-negative value, and a
+      // wild table entry still lands inside the buffer)
+      ii[k] = (int)min((uint32_t)(i0 + (ir[k] >= 0.5f ? 1 : 0)), (uint32_t)(rw - 1));
+      jj[k] = (int)min((uint32_t)(j0 + (jr[k] >= 0.5f ? 1 : 0)), (uint32_t)(rh - 1));
+      min_i[k] = (int)min((uint32_t)i0, (uint32_t)(rw - 1));
+      max_i[k] = (int)min((uint32_t)(i0 + (ir[k] > 0.0f ? 1 : 0)), (uint32_t)(rw - 1));
+      const float t = j_f + hf, ft = floorf(t);
+      // m % n for m in [n, 3n): m - n or m - 2n, whichever does not wrap below zero
+      const uint32_t m0 = (uint32_t)(int)ft - (uint32_t)rh, m1 = m0 + (t > ft ? 1u : 0u);
+      min_j[k] = (int)min(min(m0, m0 - (uint32_t)rh), (uint32_t)(rh - 1));
+      max_j[k] = (int)min(min(m1, m1 - (uint32_t)rh), (uint32_t)(rh - 1));
+      // (the last min only keeps a wild table entry inside the buffer)
+      base_i[k] = min(min_i[k], rw - 2);
+      top[k] = *reinterpret_cast<const uint2_a4 *>(
+          src + (__umul24((uint32_t)min_j[k], (uint32_t)rw) + (uint32_t)base_i[k]));
+      bot[k] = *reinterpret_cast<const uint2_a4 *>(
+          src + (__umul24((uint32_t)max_j[k], (uint32_t)rw) + (uint32_t)base_i[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < kLpRows; ++k) {
+      const int y = min(y0 + k, out_h - 1);
+      const float radius = l_rad[ii[k]];
+      const double2 c = l_cs[jj[k]];
+      const int calc_x = (int)(cxd + (double)radius * c.x);
+      const int calc_y = (int)(cyd + (double)radius * c.y);
+      exact[k] = calc_x == x && calc_y == y;
+    }
+    uint32_t out[kLpRows];
+    bool any_exact = false;
+#pragma unroll
+    for (int k = 0; k < kLpRows; ++k) {
+      const bool lo = min_i[k] == base_i[k], hi = max_i[k] == base_i[k];
+      const uint32_t tl = lo ? top[k].x : top[k].y, tr = hi ? top[k].x : top[k].y;
+      const uint32_t bl = lo ? bot[k].x : bot[k].y, br = hi ? bot[k].x : bot[k].y;
+      const f32x2_is t01 = {(float)(tl & 0xffu), (float)((tl >> 8) & 0xffu)};
+      const f32x2_is b01 = {(float)(bl & 0xffu), (float)((bl >> 8) & 0xffu)};
+      const f32x2_is u01 = {(float)(tr & 0xffu), (float)((tr >> 8) & 0xffu)};
+      const f32x2_is c01 = {(float)(br & 0xffu), (float)((br >> 8) & 0xffu)};
+      const f32x2_is t2 = {(float)((tl >> 16) & 0xffu), (float)((tr >> 16) & 0xffu)};
+      const f32x2_is b2 = {(float)((bl >> 16) & 0xffu), (float)((br >> 16) & 0xffu)};
+      const f32x2_is l01 = lerp2(t01, b01, jr[k]);  // left colour, channels 0 and 1
+      const f32x2_is r01 = lerp2(u01, c01, jr[k]);  // right colour, channels 0 and 1
+      const f32x2_is v2 = lerp2(t2, b2, jr[k]);     // channel 2: {left, right}
+      const f32x2_is h01 = lerp2(l01, r01, ir[k]);
+      const float h2 = mixf(v2.x, v2.y, ir[k]);
+      out[k] = ((uint32_t)(int)h01.x & 0xffu) | (((uint32_t)(int)h01.y & 0xffu) << 8) |
+               (((uint32_t)(int)h2 & 0xffu) << 16);
+      any_exact = any_exact | exact[k];
+    }
+    // exact hits (:53-55) are few and sit around the fovea: most waves have none.  The texel
+    // (j, i) is one of the four already here unless float rounding in `j_float + source_height`
+    // or the clamp of j at the last row says otherwise; then it is fetched.
+    if (__any(any_exact)) {
+#pragma unroll
+      for (int k = 0; k < kLpRows; ++k) {
+        const bool lo = min_i[k] == base_i[k], hi = max_i[k] == base_i[k];
+        const uint32_t tl = lo ? top[k].x : top[k].y, tr = hi ? top[k].x : top[k].y;
+        const uint32_t bl = lo ? bot[k].x : bot[k].y, br = hi ? bot[k].x : bot[k].y;
+        const bool i_lo = ii[k] == min_i[k], j_lo = jj[k] == min_j[k];
+        const bool near_hit = (i_lo | (ii[k] == max_i[k])) & (j_lo | (jj[k] == max_j[k]));
+        uint32_t hit = j_lo ? (i_lo ? tl : tr) : (i_lo ? bl : br);
+        if (exact[k] & !near_hit)
+          hit = src[__umul24((uint32_t)jj[k], (uint32_t)rw) + (uint32_t)ii[k]];
+        if (exact[k]) out[k] = hit & 0x00ffffffu;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kLpRows; ++k)
+      if (y0 + k < out_h) dst[__umul24((uint32_t)(y0 + k), (uint32_t)out_w) + (uint32_t)x0] = out[k];
   }
 }
 
@@ -573,6 +723,57 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
   const dim3 grid((target_width + 63) / 64, (target_height + 4 * kLpRows - 1) / (4 * kLpRows));
   f360::KernelSpan span(is->ctx, f360::kIsInterpolateLogpolar,
                         f360::take_profile_slot(is->ctx));
+  // "is.lp_lds": the branch-free kernel with the axis tables in LDS -- whenever the gaze lies in
+  // the frame (every offset is in the table then), the tables fit and 32-bit texel offsets do
+  const size_t lds_bytes = (size_t)source_height * 16 + (size_t)source_width * 4;
+  const int cxp = (int)cxf, cyp = (int)cyf;
+  if (is->ctx->opt_lp_lds && table.uv && cxp >= 0 && cxp <= target_width && cyp >= 0 &&
+      cyp <= target_height && source_width >= 2 && lds_bytes <= kLpLdsMax &&
+      (size_t)source_width * source_height < ((size_t)1 << 29) &&
+      (size_t)target_width * target_height < ((size_t)1 << 30) &&
+      table_bytes / sizeof(float2) < ((size_t)1 << 29)) {
+    if (!is->lp_lds_ready) {
+      F360_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void *>(is_interpolate_logpolar_lds_kernel<256>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLpLdsMax));
+      F360_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void *>(is_interpolate_logpolar_lds_kernel<512>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLpLdsMax));
+      F360_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void *>(is_interpolate_logpolar_lds_kernel<1024>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLpLdsMax));
+      int dev = 0, cus = 0;
+      F360_HIP_TRY(hipGetDevice(&dev));
+      F360_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      is->lp_cus = cus > 0 ? cus : 256;
+      is->lp_lds_ready = true;
+    }
+    // workgroup size: the tables are per workgroup, so large tables want many waves behind them
+    // (8K: 51 KB of tables, three workgroups per CU: 171 us with 256 threads, 131 with 512 or
+    // 1024, 150 for the plain kernel; 3840x1920: 33.7 / 34.6 / 34.4 against 42.3)
+    const int threads = is->ctx->opt_lp_lds > 1 ? is->ctx->opt_lp_lds : lds_bytes > 32 * 1024 ? 512 : 256;
+    const int rows_per_wg = threads / 64 * kLpRows;
+    const int tiles_x = (target_width + 63) / 64;
+    const int ntiles = tiles_x * ((target_height + rows_per_wg - 1) / rows_per_wg);
+    const int per_cu = (int)std::min<size_t>(
+        2048 / threads, std::max<size_t>(1, (160 * 1024) / (lds_bytes + 512)));
+    const int nwg = std::min(ntiles, is->lp_cus * per_cu);
+#define F360_LP_LAUNCH(T)                                                                          \
+  hipLaunchKernelGGL(is_interpolate_logpolar_lds_kernel<T>, dim3(nwg), dim3(T), lds_bytes,         \
+                     is->ctx->stream, reinterpret_cast<uint32_t *>(target_dev), target_width,      \
+                     target_height, reinterpret_cast<const uint32_t *>(source_dev), source_width,  \
+                     source_height, is->irad_dev.as<float>(), is->icos_dev.as<double>(),           \
+                     is->isin_dev.as<double>(), cxf, cyf, cxp, cyp, table, tiles_x, ntiles)
+    if (threads == 512)
+      F360_LP_LAUNCH(512);
+    else if (threads == 1024)
+      F360_LP_LAUNCH(1024);
+    else
+      F360_LP_LAUNCH(256);
+#undef F360_LP_LAUNCH
+    F360_HIP_TRY(hipGetLastError());
+    return F360_OK;
+  }
   hipLaunchKernelGGL(is_interpolate_logpolar_kernel, grid, dim3(256), 0,
                      is->ctx->stream, reinterpret_cast<uint32_t *>(target_dev),
                      target_width, target_height,

@@ -1150,6 +1150,37 @@ def test_logpolar_table_equals_direct_evaluation(f360, gpu_ctx, oracle, w, h):
     smp.close()
 
 
+@pytest.mark.parametrize("w,h", [(64, 32), (256, 128), (1920, 1080), (3840, 1920)])
+def test_logpolar_lds_kernel_equals_plain_kernel(f360, gpu_ctx, oracle, w, h):
+    """"is.lp_lds" (axis tables in LDS, paired texel loads, branch-free index arithmetic) writes
+    the bytes of the plain table kernel, exact hits included: random and smooth content, gazes in
+    the frame, on its borders and outside (the latter fall back to the plain kernel)."""
+    rw, rh = reduced(w), reduced(h)
+    a, b = gpu_ctx.malloc(w * h * 4), gpu_ctx.malloc(w * h * 4)
+    smp = f360.ImageSampler(gpu_ctx)
+    gazes = GAZES + EXTRA_GAZES + [(3.5, -2.25), (0.37, 0.61), (1.0, 0.0), (0.0, 1.0)]
+    try:
+        for frame in (oracle.lcg_frame(rw, rh, 59), smooth_frame(rw, rh)):
+            red = gpu_ctx.upload(frame)
+            for (cx, cy) in gazes if w < 3840 else gazes[:3] + gazes[-3:]:
+                gpu_ctx.set_option("is.lp_lds", 0)
+                b.fill(0x22)
+                smp.InterpolateFrameLogPolarGPU(b.ptr, w, h, 4 * w, red.ptr, rw, rh, 4 * rw, cx, cy)
+                want = b.copy_to_host(np.uint8, (h, 4 * w))
+                for mode in (1, 256, 512, 1024):  # automatic, and every workgroup size
+                    gpu_ctx.set_option("is.lp_lds", mode)
+                    a.fill(0x11)
+                    smp.InterpolateFrameLogPolarGPU(a.ptr, w, h, 4 * w, red.ptr, rw, rh, 4 * rw,
+                                                    cx, cy)
+                    assert np.array_equal(a.copy_to_host(np.uint8, (h, 4 * w)), want), (cx, cy, mode)
+            red.free()
+    finally:
+        gpu_ctx.set_option("is.lp_lds", 1)
+    a.free()
+    b.free()
+    smp.close()
+
+
 def test_gnomonic_table_equals_direct_evaluation(f360, gpu_ctx, oracle):
     """"gnomonic.table" only moves the view-independent terms into a per-geometry table."""
     w, h, tw, th = 1920, 1080, 960, 540
