@@ -146,6 +146,8 @@ _SIGNATURES = {
     "f360_debug_walk_stats": (c_int, [c_void_p, c_void_p, c_int]),
     "f360_debug_cr_math": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "f360_debug_gn_fast_sweep": (c_int, [c_void_p, c_int, ctypes.c_ulonglong, c_void_p, c_void_p]),
+    "f360_debug_gnomonic_worklist": (c_int, [c_void_p, c_void_p]),
     "f360_ctx_profile_reset": (c_int, [c_void_p]),
     "f360_tables_satdec_grid_axis": (c_int, [c_void_p, c_int, c_int]),
     "f360_tables_is_grid_axis": (c_int, [c_void_p, c_int, c_int]),
@@ -286,6 +288,20 @@ class Context:
         if n < 0:
             _check(n)
         return out[:n]
+
+    def debug_gn_fast_sweep(self, kind: int, n: int = 1 << 30):
+        """(largest |fast - double| seen, bound the guard assumes) of the gnomonic remap's float
+        asin (kind 0: every float in [-1, 1]) or atan2 (kind 1: n argument pairs)."""
+        worst, bound = ctypes.c_float(0), ctypes.c_float(0)
+        _check(lib().f360_debug_gn_fast_sweep(self._h, kind, n, ctypes.byref(worst),
+                                              ctypes.byref(bound)))
+        return worst.value, bound.value
+
+    def debug_gnomonic_worklist(self) -> int:
+        """Pixels the last GnomonicProjection call resolved with the exact chain."""
+        c = ctypes.c_uint(0)
+        _check(lib().f360_debug_gnomonic_worklist(self._h, ctypes.byref(c)))
+        return c.value
 
     def malloc(self, nbytes: int) -> "DeviceBuffer":
         return DeviceBuffer(self, nbytes)

@@ -114,6 +114,8 @@ int f360_ctx_destroy(f360_ctx *ctx) {
   if (ctx->enc.walk_err_host) (void)hipHostFree(ctx->enc.walk_err_host);
   ctx->ex_tables.release();
   ctx->gn_table.release();
+  ctx->gn_gtab.release();
+  ctx->gn_counters.release();
   ctx->ex_keys.release();
   for (const f360::ProfSpan &s : ctx->prof_pending) {
     (void)hipEventDestroy(s.a);
@@ -284,6 +286,7 @@ static const OptionSlot kOptions[] = {
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"gnomonic.fast", &f360_ctx::opt_gnomonic_fast},
+    {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},
     {"is.lp_table", &f360_ctx::opt_lp_table},
     {"is.lp_lds", &f360_ctx::opt_lp_lds},
 };

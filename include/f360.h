@@ -371,6 +371,15 @@ int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int max_units)
  * float of the exact result (elsewhere the kernels call the library routine). */
 int f360_debug_cr_math(f360_ctx *ctx, int kind, size_t n, const float *a_dev, const float *b_dev,
                        float *out_dev, uint8_t *flag_dev);
+/* Test entries for the index-guarded gnomonic remap (csrc/gn_fast_math.h, option
+ * "gnomonic.guard").  _sweep: the largest absolute error of a fast float core against double
+ * precision over a device-side sweep -- kind 0: asin over every float in [-1, 1] (n ignored);
+ * kind 1: atan2 over n pseudo-random and dense argument pairs -- and the bound the guard assumes
+ * for it.  _worklist: how many pixels of the last f360_gnomonic call made with option
+ * "debug.ablate" bit 9 set took the exact chain. */
+int f360_debug_gn_fast_sweep(f360_ctx *ctx, int kind, unsigned long long n, float *worst_out,
+                             float *bound_out);
+int f360_debug_gnomonic_worklist(f360_ctx *ctx, unsigned *count_out);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,7 @@ def test_fast_atan2_is_correctly_rounded_where_it_vouches(f360, gpu_ctx):
 def test_gnomonic_is_bit_exact_for_every_table_and_path(f360, gpu_ctx, oracle, fast, table):
     gpu_ctx.set_option("gnomonic.fast", fast)
     gpu_ctx.set_option("gnomonic.table", table)
+    gpu_ctx.set_option("gnomonic.guard", 0)   # the exact chain on every pixel
     try:
         for (w, h, tw, th) in [(256, 128, 96, 64), (1920, 1080, 960, 540), (640, 320, 333, 117)]:
             frame = oracle.lcg_frame(w, h, 808).reshape(h, w, 4)
@@ -95,3 +96,4 @@ def test_gnomonic_is_bit_exact_for_every_table_and_path(f360, gpu_ctx, oracle, f
     finally:
         gpu_ctx.set_option("gnomonic.fast", 0)
         gpu_ctx.set_option("gnomonic.table", 1)
+        gpu_ctx.set_option("gnomonic.guard", 1)
