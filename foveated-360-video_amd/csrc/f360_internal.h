@@ -109,6 +109,25 @@ struct SatEncodePlan {
 }  // namespace f360
 
 namespace f360 {
+#ifdef __HIPCC__
+// Workgroups are dealt to the 8 XCDs (each with its own L2) in launch order.  A kernel whose
+// neighbouring output rows gather from neighbouring source rows therefore pulls every source
+// sector through up to eight L2s.  This remap gives XCD k the k-th contiguous run of blocks in
+// row-major order -- a band of output rows -- instead of every eighth block ("is.xcd_bands").
+__device__ __forceinline__ void xcd_band_block(bool on, int &bx, int &by) {
+  bx = blockIdx.x;
+  by = blockIdx.y;
+  const uint32_t gx = gridDim.x, total = gx * gridDim.y;
+  if (!on || total < 64) return;
+  const uint32_t lid = blockIdx.y * gx + blockIdx.x, k = lid & 7;
+  const uint32_t idx = k * (total >> 3) + min(k, total & 7) + (lid >> 3);
+  by = (int)(idx / gx);
+  bx = (int)(idx - (uint32_t)by * gx);
+}
+#endif
+}  // namespace f360
+
+namespace f360 {
 // Kernel ids of the per-kernel timing facility (f360_ctx_profile_*).
 enum KernelId {
   kSatReduce = 0,
@@ -164,6 +183,7 @@ struct f360_ctx {
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
+  int opt_xcd_bands = 1;       // "is.xcd_bands": the point samplers give each XCD a band of output rows instead of every eighth workgroup: 0 never, 1 where it pays (log-rectilinear sampler, sources of 64 MB and more), 2 always
   int opt_lp_lds = 1;          // "is.lp_lds": log-polar un-warp keeps its axis tables in LDS (needs is.lp_table); 0 off, 1 on, 256 / 512 / 1024 = on with that workgroup size
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos), 2 two planes (sin, cos)

@@ -289,6 +289,7 @@ static const OptionSlot kOptions[] = {
     {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},
     {"is.lp_table", &f360_ctx::opt_lp_table},
     {"is.lp_lds", &f360_ctx::opt_lp_lds},
+    {"is.xcd_bands", &f360_ctx::opt_xcd_bands},
 };
 
 int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
@@ -323,6 +324,8 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
         F360_REQUIRE(value >= 1, "sat.walk_units must be >= 1: %d", value);
       if (s.field == &f360_ctx::opt_sample_fpl)
         F360_REQUIRE(value >= 1 && value <= 64, "sample.fpl out of range 1..64: %d", value);
+      if (s.field == &f360_ctx::opt_xcd_bands)
+        F360_REQUIRE(value >= 0 && value <= 2, "is.xcd_bands must be 0, 1 (automatic) or 2: %d", value);
       if (s.field == &f360_ctx::opt_lp_lds)
         F360_REQUIRE(value == 0 || value == 1 || value == 256 || value == 512 || value == 1024,
                      "is.lp_lds must be 0 (off), 1 (on) or a workgroup size 256 / 512 / 1024: %d",

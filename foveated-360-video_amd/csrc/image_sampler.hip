@@ -62,9 +62,11 @@ __global__ __launch_bounds__(256) void is_sample_rect_kernel(
     uint8_t *__restrict__ dst, int out_w, int out_h, int out_linesize, int obpp,
     const uint8_t *__restrict__ src, int src_w, int src_h, int src_linesize,
     int sbpp, const int16_t *__restrict__ gx, const int16_t *__restrict__ gy,
-    float cxf, float cyf, bool words) {
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPointRows;
+    float cxf, float cyf, bool words, bool bands) {
+  int bx, by;
+  f360::xcd_band_block(bands, bx, by);
+  const int i = bx * 64 + (threadIdx.x & 63);
+  const int j0 = (by * 4 + (threadIdx.x >> 6)) * kPointRows;
   if (i >= out_w || j0 >= out_h) return;
   int xp = (int)(cxf + (float)gx[i]);  // float add, then truncation (:24-25)
   if (xp >= src_w)
@@ -94,9 +96,11 @@ __global__ __launch_bounds__(256) void is_sample_logpolar_kernel(
     uint8_t *__restrict__ dst, int out_w, int out_h, int out_linesize, int obpp,
     const uint8_t *__restrict__ src, int src_w, int src_h, int src_linesize,
     int sbpp, const float *__restrict__ rad, const float *__restrict__ cs,
-    const float *__restrict__ sn, float cxf, float cyf, bool words) {
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPointRows;
+    const float *__restrict__ sn, float cxf, float cyf, bool words, bool bands) {
+  int bx, by;
+  f360::xcd_band_block(bands, bx, by);
+  const int i = bx * 64 + (threadIdx.x & 63);
+  const int j0 = (by * 4 + (threadIdx.x >> 6)) * kPointRows;
   if (i >= out_w || j0 >= out_h) return;
   const float r = rad[i];
   float cj[kPointRows], sj[kPointRows];
@@ -623,7 +627,12 @@ int f360_is_sample_rect(f360_image_sampler *is, uint8_t *target_dev,
                      center_x * (float)source_width,
                      center_y * (float)source_height,
                      word_pixels(target_dev, target_linesize, target_width, source_dev,
-                                 source_linesize, source_width));
+                                 source_linesize, source_width),
+                     // row bands pay where the source is far beyond the L2s (8K: 26.5 -> 20.7 us);
+                     // at 3840x1920 and below the round-robin order's balance is worth more
+                     is->ctx->opt_xcd_bands == 2 ||
+                         (is->ctx->opt_xcd_bands == 1 &&
+                          (size_t)source_linesize * source_height >= ((size_t)64 << 20)));
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }
@@ -659,7 +668,9 @@ int f360_is_sample_logpolar(f360_image_sampler *is, uint8_t *target_dev,
                      is->lsin_dev.as<float>(), center_x * (float)source_width,
                      center_y * (float)source_height,
                      word_pixels(target_dev, target_linesize, target_width, source_dev,
-                                 source_linesize, source_width));
+                                 source_linesize, source_width),
+                     // (rays, not rows: 31.5 -> 30.4 us at 8K, slower below; only when forced)
+                     is->ctx->opt_xcd_bands == 2);
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
 }

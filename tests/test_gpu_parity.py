@@ -295,8 +295,16 @@ def test_interpolate_rect_full_size_digests(f360, gpu_ctx, oracle, golden_digest
 
 
 # ------------------------------------------------------------------------- ImageSampler
+@pytest.fixture(params=[1, 0, 2])
+def xcd_bands(request, gpu_ctx):
+    """"is.xcd_bands": automatic, workgroups in launch order, one band of rows per XCD."""
+    gpu_ctx.set_option("is.xcd_bands", request.param)
+    yield request.param
+    gpu_ctx.set_option("is.xcd_bands", 1)
+
+
 @pytest.mark.parametrize("w,h,bpp", [(64, 32, 4), (256, 128, 4), (1920, 1080, 4), (200, 100, 3)])
-def test_image_sampler_point_and_logpolar(f360, gpu_ctx, oracle, w, h, bpp):
+def test_image_sampler_point_and_logpolar(f360, gpu_ctx, oracle, w, h, bpp, xcd_bands):
     rw, rh = reduced(w), reduced(h)
     frame = oracle.lcg_frame(w, h, 2024, bpp=bpp)
     smp = f360.ImageSampler(gpu_ctx)
@@ -324,6 +332,36 @@ def test_image_sampler_point_and_logpolar(f360, gpu_ctx, oracle, w, h, bpp):
     src.free()
     dst.free()
     smp.close()
+
+
+def test_point_samplers_xcd_bands_8k(f360, gpu_ctx):
+    """At 8K (where the automatic choice turns the row bands on) both point samplers write the
+    same bytes with the workgroups in launch order and remapped to one band of rows per XCD,
+    including a grid whose block count is not a multiple of 8."""
+    rng = np.random.default_rng(11)
+    for (w, h, rw, rh) in [(7680, 3840, 4272, 2144), (7680, 3840, 4100, 2001)]:
+        frame = gpu_ctx.upload(rng.integers(0, 256, (h, 4 * w), dtype=np.uint8))
+        smp = f360.ImageSampler(gpu_ctx)
+        smp.InitializeGrid(rw, rh, w, h)
+        smp.InitializeLogpolarGrid(rw, rh, w, h)
+        a, b = gpu_ctx.malloc(rw * rh * 4), gpu_ctx.malloc(rw * rh * 4)
+        try:
+            for fn in (smp.SampleFrameRectGPU, smp.SampleFrameLogPolarGPU):
+                for (cx, cy) in [(0.5, 0.5), (0.0, 1.0), (0.83, 0.21)]:
+                    gpu_ctx.set_option("is.xcd_bands", 0)
+                    a.fill(0x5A)
+                    fn(a.ptr, rw, rh, 4 * rw, frame.ptr, w, h, 4 * w, cx, cy)
+                    for mode in (1, 2):
+                        gpu_ctx.set_option("is.xcd_bands", mode)
+                        b.fill(0x5A)
+                        fn(b.ptr, rw, rh, 4 * rw, frame.ptr, w, h, 4 * w, cx, cy)
+                        assert np.array_equal(a.copy_to_host(np.uint8, (rh, 4 * rw)),
+                                              b.copy_to_host(np.uint8, (rh, 4 * rw))), (cx, cy, mode)
+        finally:
+            gpu_ctx.set_option("is.xcd_bands", 1)
+        for buf in (frame, a, b):
+            buf.free()
+        smp.close()
 
 
 def smooth_frame(w, h):
