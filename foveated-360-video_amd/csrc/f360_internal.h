@@ -187,7 +187,7 @@ struct f360_ctx {
   int opt_lp_lds = 1;          // "is.lp_lds": log-polar un-warp keeps its axis tables in LDS (needs is.lp_table); 0 off, 1 on, 256 / 512 / 1024 = on with that workgroup size
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos), 2 two planes (sin, cos)
-  int opt_gnomonic_guard = 1;  // "gnomonic.guard": texel indices from a cheap float evaluation wherever its error bound decides them, the exact chain for the worklist of the others
+  int opt_gnomonic_guard = 1;  // "gnomonic.guard": texel indices from a cheap float evaluation wherever its error bound decides them, the exact chain for the others (64 at a time)
   int opt_gnomonic_fast = 0;   // "gnomonic.fast": asin / atan2 through cr_math.h (cheap double evaluation + rounding guard, library routine for the rejected lanes)
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX

@@ -7,7 +7,7 @@
 // and a few more float roundings; every one of those moves the final product by a bounded
 // amount.  So the index is known for certain from a CHEAP evaluation of the same real-valued
 // chain whenever that evaluation lands further from an integer than the sum of the bounds --
-// and only the pixels that land closer (about 1 in 100) need the exact chain.  The arguments of
+// and only the pixels that land closer (1.5 in 100 at 8K) need the exact chain.  The arguments of
 // asin and atan2 are computed with the kernel text's own float operations, so they are the same
 // floats in both evaluations: no condition number enters.
 //

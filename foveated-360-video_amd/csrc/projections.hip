@@ -425,7 +425,7 @@ extern "C" int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_widt
   uint32_t *dst = reinterpret_cast<uint32_t *>(target_dev);
   const uint32_t *src = reinterpret_cast<const uint32_t *>(source_dev);
   const bool fast = ctx->opt_gnomonic_fast != 0;
-  // "gnomonic.guard": the index-guarded remap + worklist, for a gaze inside the frame
+  // "gnomonic.guard": the index-guarded remap, for a gaze inside the frame
   // (|lambda0| <= pi is what its error budget assumes) and 32-bit pixel indices
   const size_t npix = (size_t)target_width * target_height;
   if (ctx->opt_gnomonic_guard && std::fabs(lambda0) <= 3.1415928f && npix < ((size_t)1 << 31)) {
@@ -542,9 +542,10 @@ extern "C" int f360_gnomonic(f360_ctx *ctx, uint8_t *target_dev, int target_widt
   return F360_OK;
 }
 
-// Test entries for csrc/gn_fast_math.h and the worklist: the largest absolute error of a fast core
+// Test entries for csrc/gn_fast_math.h and the guarded remap: the largest absolute error of a fast core
 // over the sweep of `kind` (see gn_fast_sweep_kernel; blocks until done), the bounds the guard
-// uses, and the length of the last worklist.  Not part of the reference surface.
+// uses, and how many pixels of the last counted launch took the exact chain.  Not part of the
+// reference surface.
 extern "C" int f360_debug_gn_fast_sweep(f360_ctx *ctx, int kind, unsigned long long n,
                                         float *worst_out, float *bound_out) {
   F360_REQUIRE(ctx && worst_out && bound_out && (kind == 0 || kind == 1),
