@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void gnomonic_kernel(
 // fast products lie further than the guard from every integer (0 and the size included: that
 // also keeps the fast and the exact value on the same side of the fmod wrap) and further than
 // 2e-6 of the size from the clamp at 0.999; beyond the clamp the index is the constant
-// (int)(0.999f * size).  Everything else -- about 1.5 pixels in 100, plus NaN / out-of-domain
+// (int)(0.999f * size) -- for u only up to one guard before the wrap at the right edge (found
+// by scripts/gn_guard_soak.py: the centre row of a view onto a pole runs along the seam).  Everything else -- about 1.5 pixels in 100, plus NaN / out-of-domain
 // arguments -- goes through the exact chain, 64 at a time (see the kernel).  Built and measured
 // on the way: a second launch over a global worklist (its exact pass is latency-bound at 15-17 us
 // whatever the list length; one global counter serialised ~60,000 atomics: 560 us; 1024 lists:
@@ -300,7 +301,9 @@ __global__ __launch_bounds__(kGnThreads) void gnomonic_guard_kernel(
       const float frv = fv - flv, fru = fu - flu;
       const bool in_v = frv >= g.dv && frv <= 1.0f - g.dv && fv < g.clamp_lo_v;
       const bool in_u = fru >= g.du && fru <= 1.0f - g.du && fu < g.clamp_lo_u;
-      const bool top_v = fv > g.clamp_hi_v, top_u = fu > g.clamp_hi_u;
+      // (beyond the clamp u still has the fmod wrap at the right edge ahead of it: a value that
+      // the exact chain may already have wrapped to 0 must not be taken for a clamped one)
+      const bool top_v = fv > g.clamp_hi_v, top_u = fu > g.clamp_hi_u && fu < g.ku - g.du;
       const int iy = top_v ? g.kclamp_v : (int)flv;
       const int ix = top_u ? g.kclamp_u : (int)flu;
       ok = ok && (in_v || top_v) && (in_u || top_u);

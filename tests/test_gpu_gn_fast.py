@@ -89,3 +89,31 @@ def test_guarded_remap_repeated_calls_and_geometry_changes(f360, gpu_ctx, oracle
             assert int((got != want).any(axis=2).sum()) == 0, (tw, th, k)
         dst.free()
     src.free()
+
+
+def test_guarded_remap_along_the_seam(f360, gpu_ctx):
+    """A view centred on a pole with the gaze a quarter turn from the seam: the centre row of the
+    viewport (y == 0 for an even height) runs exactly along the source's left / right edge, where
+    atan2 sits at +-pi/2 and su at the fmod wrap, beyond the clamp at 0.999.  (Found by
+    scripts/gn_guard_soak.py: a clamped index must not be accepted within a guard of the wrap.)"""
+    w, h = 7680, 3840
+    rng = np.random.default_rng(3)
+    src = gpu_ctx.upload(rng.integers(0, 256, (h, 4 * w), dtype=np.uint8))
+    proj = f360.Projections(gpu_ctx)
+    try:
+        for (tw, th) in [(746, 526), (1024, 512), (333, 118)]:
+            a, b = gpu_ctx.malloc(tw * th * 4), gpu_ctx.malloc(tw * th * 4)
+            for cx in (0.75, 0.25, 0.0, 0.5, 1.0):
+                for cy in (0.0, 1.0):
+                    gpu_ctx.set_option("gnomonic.guard", 1)
+                    proj.GnomonicProjection(a.ptr, tw, th, 4 * tw, src.ptr, w, h, 4 * w, cx, cy)
+                    gpu_ctx.set_option("gnomonic.guard", 0)
+                    proj.GnomonicProjection(b.ptr, tw, th, 4 * tw, src.ptr, w, h, 4 * w, cx, cy)
+                    ga = a.copy_to_host(np.uint8, (th, 4 * tw))
+                    gb = b.copy_to_host(np.uint8, (th, 4 * tw))
+                    assert np.array_equal(ga, gb), (tw, th, cx, cy, int((ga != gb).sum()))
+            a.free()
+            b.free()
+    finally:
+        gpu_ctx.set_option("gnomonic.guard", 1)
+    src.free()
