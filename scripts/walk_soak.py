@@ -1,0 +1,67 @@
+"""Soak of the read-once batched encoder against the three kernels: random frame geometries, batch
+sizes, row paddings and encoder options (kernel variant, batches in flight, frames per launch);
+every table compared in full on the host against numpy's own summed-area table of the frame
+(mod 2^32), so both encoders are checked, not only against each other.
+    python scripts/walk_soak.py [seconds] [seed]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import f360_amd as f360
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda", 0)
+t0 = time.time()
+cases = frames_done = bad = 0
+worst = None
+ctx = f360.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+enc = f360.SATEncoder(ctx)
+while time.time() - t0 < budget:
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        w, h = 4 * int(rng.integers(1, 300)), int(rng.integers(1, 300))
+    elif kind == 1:
+        w, h = 4 * int(rng.integers(200, 2100)), int(rng.integers(1, 70))
+    else:
+        w, h = 4 * int(rng.integers(1, 80)), int(rng.integers(300, 3000))
+    count = int(rng.integers(1, 41))
+    while count * w * h * 12 > 400e6:
+        count = max(1, count // 2)
+    pad = 16 * int(rng.integers(0, 3))
+    if pad >= w:   # (bytes per pixel = linesize / width, as in the reference: keep it at 4)
+        pad = 0
+    linesize = 4 * w + pad
+    src = torch.empty((count, h, linesize), dtype=torch.uint8, device=dev)
+    src.random_(0, 256)
+    if rng.integers(0, 8) == 0:
+        src[int(rng.integers(0, count))].fill_(255)
+    tabs = [torch.zeros((count, h, w, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+    opts = {"sat.walk_variant": int(rng.choice([1, 2])), "sat.walk_depth": int(rng.choice([2, 3])),
+            "sat.walk_frames": int(rng.choice([0, 0, 1, 3, 8, 64]))}
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    for walk in (1, 0):
+        ctx.set_option("sat.walk", walk)
+        enc.EncodeFramesGPU([tabs[1 - walk][k].data_ptr() for k in range(count)],
+                            [src[k].data_ptr() for k in range(count)], w, h, linesize)
+    ctx.finish()
+    px = src[:, :, :4 * w].reshape(count, h, w, 4)[..., :3].to(torch.int64)
+    want = px.cumsum(dim=2).cumsum(dim=1).to(torch.int32)  # wraps like uint32
+    ok_walk = bool(torch.equal(tabs[0], want))
+    ok_three = bool(torch.equal(tabs[1], want))
+    cases += 1
+    frames_done += count
+    if not (ok_walk and ok_three):
+        bad += 1
+        worst = worst or []
+        if len(worst) < 12:
+            worst.append((w, h, count, linesize, opts, ok_walk, ok_three))
+    del src, tabs, px, want
+for k, v in (("sat.walk", -1), ("sat.walk_variant", 1), ("sat.walk_depth", 2), ("sat.walk_frames", 0)):
+    ctx.set_option(k, v)
+print({"cases": cases, "frames": frames_done, "bad_cases": bad, "first_failures": worst,
+       "seconds": round(time.time() - t0, 1)})
+sys.exit(1 if bad else 0)
