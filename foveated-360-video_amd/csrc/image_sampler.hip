@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void is_interpolate_logpolar_kernel(
 // i_float and j_float are never negative (log of a radius >= 1; fmod of a positive number; a
 // positive constant), which round() as floor + (fraction >= 0.5) relies on.
 constexpr uint32_t kLpLdsMax = 96 * 1024;
+constexpr int kLpLdsRows = 2;  // output rows per thread (8K: 148 us with 8, 130 with 4, 122 with 2, 137 with 1)
 
 __device__ __forceinline__ f32x2_is lerp2(f32x2_is a, f32x2_is b, float t) {
   return a + (b - a) * t;  // -ffp-contract=off: sub, mul, add like mix()
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(THREADS) void is_interpolate_logpolar_lds_kernel(
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * 64 + lane;
-    const int y0 = (ty * (THREADS / 64) + wave) * kLpRows;
+    const int y0 = (ty * (THREADS / 64) + wave) * kLpLdsRows;
     if (x0 >= out_w || y0 >= out_h) continue;
     int x = x0;
     if (x - cxp > out_w / 2)
@@ -333,22 +334,22 @@ __global__ __launch_bounds__(THREADS) void is_interpolate_logpolar_lds_kernel(
     const int dx = x - cxp;
     const uint32_t col = (uint32_t)min(max(dx + table.span_x, 0), 2 * table.span_x);
 
-    float2 uv[kLpRows];
+    float2 uv[kLpLdsRows];
 #pragma unroll
-    for (int k = 0; k < kLpRows; ++k) {
+    for (int k = 0; k < kLpLdsRows; ++k) {
       const int dy = min(y0 + k, out_h - 1) - cyp;
       const uint32_t row = (uint32_t)min(max(dy + table.span_y, 0), 2 * table.span_y);
       // (24-bit multiplies are full rate, 32-bit ones quarter rate: rows, pitches and widths
       // are below 2^17 + 4, the products below 2^29 -- host check)
       uv[k] = table.uv[__umul24(row, (uint32_t)table.pitch) + col];
     }
-    int ii[kLpRows], jj[kLpRows], min_i[kLpRows], max_i[kLpRows], min_j[kLpRows], max_j[kLpRows];
-    float ir[kLpRows], jr[kLpRows];
-    bool exact[kLpRows];
-    uint2 top[kLpRows], bot[kLpRows];
-    int base_i[kLpRows];
+    int ii[kLpLdsRows], jj[kLpLdsRows], min_i[kLpLdsRows], max_i[kLpLdsRows], min_j[kLpLdsRows], max_j[kLpLdsRows];
+    float ir[kLpLdsRows], jr[kLpLdsRows];
+    bool exact[kLpLdsRows];
+    uint2 top[kLpLdsRows], bot[kLpLdsRows];
+    int base_i[kLpLdsRows];
 #pragma unroll
-    for (int k = 0; k < kLpRows; ++k) {
+    for (int k = 0; k < kLpLdsRows; ++k) {
       const float i_f = uv[k].x, j_f = uv[k].y;
       const float fi = floorf(i_f), fj = floorf(j_f);
       ir[k] = i_f - fi;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(THREADS) void is_interpolate_logpolar_lds_kernel(
           src + (__umul24((uint32_t)max_j[k], (uint32_t)rw) + (uint32_t)base_i[k]));
     }
 #pragma unroll
-    for (int k = 0; k < kLpRows; ++k) {
+    for (int k = 0; k < kLpLdsRows; ++k) {
       const int y = min(y0 + k, out_h - 1);
       const float radius = l_rad[ii[k]];
       const double2 c = l_cs[jj[k]];
@@ -381,10 +382,10 @@ __global__ __launch_bounds__(THREADS) void is_interpolate_logpolar_lds_kernel(
       const int calc_y = (int)(cyd + (double)radius * c.y);
       exact[k] = calc_x == x && calc_y == y;
     }
-    uint32_t out[kLpRows];
+    uint32_t out[kLpLdsRows];
     bool any_exact = false;
 #pragma unroll
-    for (int k = 0; k < kLpRows; ++k) {
+    for (int k = 0; k < kLpLdsRows; ++k) {
       const bool lo = min_i[k] == base_i[k], hi = max_i[k] == base_i[k];
       const uint32_t tl = lo ? top[k].x : top[k].y, tr = hi ? top[k].x : top[k].y;
       const uint32_t bl = lo ? bot[k].x : bot[k].y, br = hi ? bot[k].x : bot[k].y;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(THREADS) void is_interpolate_logpolar_lds_kernel(
     // or the clamp of j at the last row says otherwise; then it is fetched.
     if (__any(any_exact)) {
 #pragma unroll
-      for (int k = 0; k < kLpRows; ++k) {
+      for (int k = 0; k < kLpLdsRows; ++k) {
         const bool lo = min_i[k] == base_i[k], hi = max_i[k] == base_i[k];
         const uint32_t tl = lo ? top[k].x : top[k].y, tr = hi ? top[k].x : top[k].y;
         const uint32_t bl = lo ? bot[k].x : bot[k].y, br = hi ? bot[k].x : bot[k].y;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(THREADS) void is_interpolate_logpolar_lds_kernel(
       }
     }
 #pragma unroll
-    for (int k = 0; k < kLpRows; ++k)
+    for (int k = 0; k < kLpLdsRows; ++k)
       if (y0 + k < out_h) dst[__umul24((uint32_t)(y0 + k), (uint32_t)out_w) + (uint32_t)x0] = out[k];
   }
 }
@@ -760,10 +761,10 @@ int f360_is_interpolate_logpolar(f360_image_sampler *is, uint8_t *target_dev,
       is->lp_lds_ready = true;
     }
     // workgroup size: the tables are per workgroup, so large tables want many waves behind them
-    // (8K: 51 KB of tables, three workgroups per CU: 171 us with 256 threads, 131 with 512 or
-    // 1024, 150 for the plain kernel; 3840x1920: 33.7 / 34.6 / 34.4 against 42.3)
-    const int threads = is->ctx->opt_lp_lds > 1 ? is->ctx->opt_lp_lds : lds_bytes > 32 * 1024 ? 512 : 256;
-    const int rows_per_wg = threads / 64 * kLpRows;
+    // (with two rows per thread: 8K 153 / 122 / 120 us for 256 / 512 / 1024 threads, 3840x1920
+    // 33.6 / 31.5 / 31.4, 1920x1080 12.8 / 11.9 / 11.8 -- 512 everywhere)
+    const int threads = is->ctx->opt_lp_lds > 1 ? is->ctx->opt_lp_lds : 512;
+    const int rows_per_wg = threads / 64 * kLpLdsRows;
     const int tiles_x = (target_width + 63) / 64;
     const int ntiles = tiles_x * ((target_height + rows_per_wg - 1) / rows_per_wg);
     const int per_cu = (int)std::min<size_t>(
