@@ -15,7 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda", 0)
 t0 = time.time()
-cases = frames_done = bad = 0
+cases = frames_done = bad = planar_cases = 0
 worst = None
 ctx = f360.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 enc = f360.SATEncoder(ctx)
@@ -43,6 +43,30 @@ while time.time() - t0 < budget:
             "sat.walk_frames": int(rng.choice([0, 0, 1, 3, 8, 64]))}
     for k, v in opts.items():
         ctx.set_option(k, v)
+    if rng.integers(0, 4) == 0 and w % 8 == 0 and h % 2 == 0:
+        # planar YUV 4:2:0 source, either libswscale model: the read-once encoder against the
+        # three kernels (the conversion itself has its own parity tests against the oracle)
+        ctx.set_option("yuv.model", int(rng.integers(0, 2)))
+        yl, cl = w + 16 * int(rng.integers(0, 2)), w // 2 + 16 * int(rng.integers(0, 2))
+        ys = torch.empty((count, h, yl), dtype=torch.uint8, device=dev).random_(0, 256)
+        us = torch.empty((count, h // 2, cl), dtype=torch.uint8, device=dev).random_(0, 256)
+        vs = torch.empty((count, h // 2, cl), dtype=torch.uint8, device=dev).random_(0, 256)
+        for walk in (1, 0):
+            ctx.set_option("sat.walk", walk)
+            enc.EncodeFramesYUV420PGPU([tabs[1 - walk][k].data_ptr() for k in range(count)],
+                                       [(ys[k].data_ptr(), us[k].data_ptr(), vs[k].data_ptr()) for k in range(count)],
+                                       yl, cl, cl, w, h)
+        ctx.finish()
+        cases += 1
+        frames_done += count
+        planar_cases += 1
+        if not torch.equal(tabs[0], tabs[1]):
+            bad += 1
+            worst = worst or []
+            if len(worst) < 12:
+                worst.append(("yuv420p", w, h, count, yl, cl, opts))
+        del src, tabs, ys, us, vs
+        continue
     for walk in (1, 0):
         ctx.set_option("sat.walk", walk)
         enc.EncodeFramesGPU([tabs[1 - walk][k].data_ptr() for k in range(count)],
@@ -62,6 +86,6 @@ while time.time() - t0 < budget:
     del src, tabs, px, want
 for k, v in (("sat.walk", -1), ("sat.walk_variant", 1), ("sat.walk_depth", 2), ("sat.walk_frames", 0)):
     ctx.set_option(k, v)
-print({"cases": cases, "frames": frames_done, "bad_cases": bad, "first_failures": worst,
+print({"cases": cases, "planar_cases": planar_cases, "frames": frames_done, "bad_cases": bad, "first_failures": worst,
        "seconds": round(time.time() - t0, 1)})
 sys.exit(1 if bad else 0)
