@@ -76,6 +76,19 @@ def asin32(a, c):
     return np.where(small, p, np.copysign(big, a)).astype(f32)
 
 
+def estimate(atan_terms=9, asin_terms=5, n=4_000_001, seed=3):
+    """(Q, R, max |atan core error|, max |asin error|) on grids of about n points each."""
+    rng = np.random.default_rng(seed)
+    q = cheb_fit(atan_q, 1.0002, atan_terms)
+    t = np.concatenate([np.linspace(0, 1, n), rng.uniform(0, 1, n)]).astype(f32)
+    e_at = float(np.max(np.abs(atan_core32(t, q).astype(ld) - np.arctan(t.astype(ld)))))
+    r = cheb_fit(asin_r, 0.2502, asin_terms)
+    a = np.concatenate([np.linspace(-1, 1, 2 * n), rng.uniform(-1, 1, n),
+                        1 - np.logspace(-9, -1, 200_001), np.logspace(-9, -0.31, 200_001)]).astype(f32)
+    e_as = float(np.max(np.abs(asin32(a, r).astype(ld) - np.arcsin(a.astype(ld)))))
+    return q, r, e_at, e_as
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--atan-terms", type=int, default=9)
