@@ -12,7 +12,7 @@ against long double and prints the largest absolute error.  The device test
 (tests/test_gpu_gn_fast.py) sweeps the device functions themselves (hardware rcp / sqrt); the
 bound the kernel uses is a multiple of what both report.
 
-    python tools/fit_gn_fast.py [--atan-terms 9] [--asin-terms 6] [--emit]
+    python tools/fit_gn_fast.py [--atan-terms 9] [--asin-terms 5] [--emit]
 """
 import argparse
 
@@ -92,7 +92,7 @@ def estimate(atan_terms=9, asin_terms=5, n=4_000_001, seed=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--atan-terms", type=int, default=9)
-    ap.add_argument("--asin-terms", type=int, default=6)
+    ap.add_argument("--asin-terms", type=int, default=5)
     ap.add_argument("--emit", action="store_true")
     args = ap.parse_args()
     rng = np.random.default_rng(3)
