@@ -144,8 +144,6 @@ _SIGNATURES = {
     "f360_ctx_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "f360_ctx_profile_frames": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "f360_debug_walk_stats": (c_int, [c_void_p, c_void_p, c_int]),
-    "f360_debug_cr_math": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_void_p, c_void_p,
-                                   c_void_p]),
     "f360_debug_gn_fast_sweep": (c_int, [c_void_p, c_int, ctypes.c_ulonglong, c_void_p, c_void_p]),
     "f360_debug_gnomonic_worklist": (c_int, [c_void_p, c_void_p]),
     "f360_ctx_profile_reset": (c_int, [c_void_p]),

@@ -175,7 +175,6 @@ struct f360_ctx {
   int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows
   int opt_walk_units = 960;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder
   int opt_walk_frames = 0;     // "sat.walk_frames": most frames one read-once launch takes (1..64); 0 = about 1024 strip owners, one per SIMD
-  int opt_walk_variant = 1;    // "sat.walk_variant": read-once kernel for RGB0 frames: 1 sat_walk_kernel, 2 sat_walk2_kernel (LDS-DMA pixels and polls, exact wait counts: no per-batch store drain)
   int opt_walk_depth = 2;      // "sat.walk_depth": 8-row batches a strip owner rotates through (2 | 3), all but one in flight
   int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
@@ -186,9 +185,8 @@ struct f360_ctx {
   int opt_xcd_bands = 1;       // "is.xcd_bands": the point samplers give each XCD a band of output rows instead of every eighth workgroup: 0 never, 1 where it pays (log-rectilinear sampler, sources of 64 MB and more), 2 always
   int opt_lp_lds = 1;          // "is.lp_lds": log-polar un-warp keeps its axis tables in LDS (needs is.lp_table); 0 off, 1 on, 256 / 512 / 1024 = on with that workgroup size
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
-  int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos), 2 two planes (sin, cos)
+  int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos)
   int opt_gnomonic_guard = 1;  // "gnomonic.guard": texel indices from a cheap float evaluation wherever its error bound decides them, the exact chain for the others (64 at a time)
-  int opt_gnomonic_fast = 0;   // "gnomonic.fast": asin / atan2 through cr_math.h (cheap double evaluation + rounding guard, library routine for the rejected lanes)
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
@@ -196,11 +194,11 @@ struct f360_ctx {
   int ex_w = 0, ex_h = 0, ex_tw = 0, ex_th = 0, ex_kind = -1;
   f360::DevBuf ex_tables, ex_keys;
   // gnomonic remap: view-independent per-pixel terms of one target geometry (projections.hip)
-  int gn_w = 0, gn_h = 0, gn_kind = 0;
+  int gn_w = 0, gn_h = 0;
   f360::DevBuf gn_table;
   // index-guarded remap ("gnomonic.guard"): rho / sin / cos planes + the two screen axes of one
   // target geometry; a debug word (rejected pixels of the last counted launch)
-  int gn_gw = 0, gn_gh = 0, gn_cus = 0, gn_wg_per_cu[2] = {0, 0};
+  int gn_gw = 0, gn_gh = 0, gn_cus = 0, gn_wg_per_cu = 0;
   f360::DevBuf gn_gtab, gn_counters;
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;

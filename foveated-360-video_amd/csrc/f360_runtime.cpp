@@ -276,7 +276,6 @@ static const OptionSlot kOptions[] = {
     {"sat.walk", &f360_ctx::opt_walk},
     {"sat.walk_units", &f360_ctx::opt_walk_units},
     {"sat.walk_depth", &f360_ctx::opt_walk_depth},
-    {"sat.walk_variant", &f360_ctx::opt_walk_variant},
     {"sat.walk_frames", &f360_ctx::opt_walk_frames},
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"interp.rows", &f360_ctx::opt_interp_rows},
@@ -285,7 +284,6 @@ static const OptionSlot kOptions[] = {
     {"yuv.model", &f360_ctx::opt_yuv_model},
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
-    {"gnomonic.fast", &f360_ctx::opt_gnomonic_fast},
     {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},
     {"is.lp_table", &f360_ctx::opt_lp_table},
     {"is.lp_lds", &f360_ctx::opt_lp_lds},
@@ -316,8 +314,6 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
         F360_REQUIRE(value >= -1 && value <= 1, "sat.walk must be -1 (automatic), 0 or 1: %d", value);
       if (s.field == &f360_ctx::opt_walk_depth)
         F360_REQUIRE(value >= 2 && value <= 3, "sat.walk_depth must be 2 or 3: %d", value);
-      if (s.field == &f360_ctx::opt_walk_variant)
-        F360_REQUIRE(value == 1 || value == 2, "sat.walk_variant must be 1 or 2: %d", value);
       if (s.field == &f360_ctx::opt_walk_frames)
         F360_REQUIRE(value >= 0 && value <= 64, "sat.walk_frames out of range 0..64: %d", value);
       if (s.field == &f360_ctx::opt_walk_units)

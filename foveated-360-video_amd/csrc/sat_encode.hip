@@ -1050,8 +1050,6 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
   }
 }
 
-#include "sat_walk_nodrain.h"
-
 int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false, int frames = 1) {
   f360::SatEncodePlan &p = ctx->enc;
   // band height: the largest of 64 / 32 / 16 rows that still yields enough tiles (one wave
@@ -1415,9 +1413,6 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
       F360_WALK_LAUNCH(kSrcYuvSwsX86);
     else if (yuv_src == kSrcYuvSwsC)
       F360_WALK_LAUNCH(kSrcYuvSwsC);
-    else if (ctx->opt_walk_variant == 2)  // no per-batch store drain (sat_walk_nodrain.h)
-      hipLaunchKernelGGL(sat_walk2_kernel, dim3((a.walk_units + kW2Waves - 1) / kW2Waves),
-                         dim3(64 * kW2Waves), 0, ctx->stream, a, wb);
     else
       F360_WALK_LAUNCH(kSrcRgb0);
 #undef F360_WALK_LAUNCH

@@ -365,12 +365,6 @@ int f360_ctx_profile_reset(f360_ctx *ctx);
  * that took the slow path, polls spent in them (4 x 64-bit words per unit, launch order).
  * Returns the number of units written (<= max_units), or a negative status. */
 int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int max_units);
-/* Test entry for the fast correctly rounded float asin / atan2 of the non-separable remaps
- * (csrc/cr_math.h): kind 0 asin(a_dev[i]), kind 1 atan2(a_dev[i], b_dev[i]); out_dev[i] = the
- * float the routine returns, flag_dev[i] = 1 where it vouches that this is the correctly rounded
- * float of the exact result (elsewhere the kernels call the library routine). */
-int f360_debug_cr_math(f360_ctx *ctx, int kind, size_t n, const float *a_dev, const float *b_dev,
-                       float *out_dev, uint8_t *flag_dev);
 /* Test entries for the index-guarded gnomonic remap (csrc/gn_fast_math.h, option
  * "gnomonic.guard").  _sweep: the largest absolute error of a fast float core against double
  * precision over a device-side sweep -- kind 0: asin over every float in [-1, 1] (n ignored);

@@ -240,7 +240,6 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
         gpu_ctx.set_option("sat.walk", 1 if case % 2 else -1)
         gpu_ctx.set_option("sat.walk_depth", int(rng.choice([2, 3])))
         gpu_ctx.set_option("sat.walk_frames", int(rng.choice([0, 1, 3, 7, 64])))
-        gpu_ctx.set_option("sat.walk_variant", int(rng.choice([1, 2])))
         frames = [rng.integers(0, 256, (h, ls), dtype=np.uint8) for _ in range(n)]
         gazes = [random_gaze(rng) for _ in range(n)]
         srcs = [gpu_ctx.upload(f) for f in frames]
@@ -267,7 +266,6 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
     gpu_ctx.set_option("sat.walk", -1)
     gpu_ctx.set_option("sat.walk_depth", 2)
     gpu_ctx.set_option("sat.walk_frames", 0)
-    gpu_ctx.set_option("sat.walk_variant", 1)
 
 
 def test_random_output_colour_step(f360, gpu_ctx, oracle):

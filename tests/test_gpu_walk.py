@@ -31,17 +31,13 @@ def _encode_batch_and_check(f360, ctx, oracle, w, h, n, pad=0, seed=900, frames=
     return bad
 
 
-@pytest.fixture(params=[1, 2], ids=["walk_kernel", "nodrain_kernel"])
-def walk_ctx(gpu_ctx, request):
-    """Both read-once kernels (sat.walk_variant): sat_walk_kernel, and sat_walk2_kernel with
-    LDS-DMA loads and exact wait counts (RGB0 frames; planar sources take the first either way)."""
-    default = gpu_ctx.get_option("sat.walk_variant")
+@pytest.fixture
+def walk_ctx(gpu_ctx):
+    """A context that takes the read-once kernel for every batched encode, whatever its size."""
     gpu_ctx.set_option("sat.walk", 1)
-    gpu_ctx.set_option("sat.walk_variant", request.param)
     yield gpu_ctx
     gpu_ctx.set_option("sat.walk", -1)
     gpu_ctx.set_option("sat.walk_depth", 2)
-    gpu_ctx.set_option("sat.walk_variant", default)
 
 
 @pytest.mark.parametrize("w,h,n,pad", [
@@ -92,13 +88,11 @@ def test_walk_special_frames(f360, walk_ctx, oracle):
     assert _encode_batch_and_check(f360, walk_ctx, oracle, w, h, 3, frames=frames) == []
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_walk_under_uneven_load(f360, oracle, variant):
+def test_walk_under_uneven_load(f360, oracle):
     """A second context on its own stream streams through memory while the strip owners hand
     their prefixes along: hand-offs must not depend on timing or placement."""
     with f360.Context(0) as a, f360.Context(0) as b:
         a.set_option("sat.walk", 1)
-        a.set_option("sat.walk_variant", variant)
         w, h, n = 2304, 256, 24
         frames = [oracle.lcg_frame(w, h, 300 + k) for k in range(n)]
         srcs = [a.upload(f) for f in frames]
@@ -140,19 +134,16 @@ def test_walk_equals_three_kernel_encoder_at_8k(f360, gpu_ctx, oracle, golden_di
     sats = [gpu_ctx.malloc(w * h * 12) for _ in frames]
     enc = f360.SATEncoder(gpu_ctx)
     out = {}
-    default = gpu_ctx.get_option("sat.walk_variant")
-    for walk in (0, 1, 2):   # three kernels, sat_walk_kernel, sat_walk2_kernel
-        gpu_ctx.set_option("sat.walk", min(walk, 1))
-        gpu_ctx.set_option("sat.walk_variant", max(walk, 1))
+    for walk in (0, 1):   # three kernels, sat_walk_kernel
+        gpu_ctx.set_option("sat.walk", walk)
         for s in sats:
             s.fill(0x5A)
         enc.EncodeFramesGPU([s.ptr for s in sats], [s.ptr for s in srcs], w, h, 4 * w)
         out[walk] = [f"{oracle.fnv1a64(s.copy_to_host(np.uint32, (h, w, 3))):016x}" for s in sats]
     gpu_ctx.set_option("sat.walk", -1)
-    gpu_ctx.set_option("sat.walk_variant", default)
     for b in srcs + sats:
         b.free()
-    assert out[0] == out[1] == out[2]
+    assert out[0] == out[1]
     assert out[1][1] == ent["sat"] and out[1][2] == ent["sat_white"]
 
 
@@ -206,8 +197,7 @@ def test_config4_batch_through_the_automatic_choice(f360, oracle):
     assert res["bad_frames"] == [], res
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_two_walker_launches_share_the_device(f360, oracle, variant):
+def test_two_walker_launches_share_the_device(f360, oracle):
     """Two contexts (two streams) run read-once launches at the same time: workgroups of one
     launch occupy SIMDs the other's later tickets are waiting for.  A strip only ever waits for a
     unit whose workgroup is already running, so both drain and both are right."""
@@ -218,7 +208,6 @@ def test_two_walker_launches_share_the_device(f360, oracle, variant):
     def worker(tag, seed):
         with f360.Context(0) as ctx:
             ctx.set_option("sat.walk", 1)
-            ctx.set_option("sat.walk_variant", variant)
             frames = [oracle.lcg_frame(w, h, seed + k) for k in range(n)]
             srcs = [ctx.upload(f) for f in frames]
             sats = [ctx.malloc(w * h * 12) for _ in range(n)]
@@ -246,8 +235,7 @@ def test_two_walker_launches_share_the_device(f360, oracle, variant):
     assert results == {0: [], 1: []}, results
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_walker_launch_replays_from_a_hip_graph(f360, oracle, variant):
+def test_walker_launch_replays_from_a_hip_graph(f360, oracle):
     """Nothing a read-once launch needs comes from the host per launch -- ticket, retirement count
     and the serial that tags its hand-off granules live in device memory and are advanced by the
     launches themselves -- so a captured launch (kernel arguments frozen) replays correctly, any
@@ -270,7 +258,6 @@ def test_walker_launch_replays_from_a_hip_graph(f360, oracle, variant):
     with torch.cuda.stream(side):
         ctx = f360.Context(0, stream=side.cuda_stream)
         ctx.set_option("sat.walk", 1)
-        ctx.set_option("sat.walk_variant", variant)
         enc = f360.SATEncoder(ctx)
         fp = [frames[k].data_ptr() for k in range(n)]
         sp = [s.data_ptr() for s in sats]
