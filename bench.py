@@ -388,7 +388,13 @@ def main():
     my_elapsed = elapsed
     elapsed, total_px = sharding.reduce_run(elapsed, float(args.steps) * B * w * h,
                                             device=dev if args.backend == "nccl" else None)
-    per_rank = sharding.gather_run(my_elapsed, B, device=dev if args.backend == "nccl" else None)
+    # every context drained through the library's own sync (an error of any enqueued call
+    # surfaces here and ends the run with a non-zero status), and the strips of the read-once
+    # encoder that had to finish without their hand-off counted (exact either way; time lost)
+    recoveries = 0
+    for c in ctxs:
+        c.finish()
+        recoveries += c.debug_walk_recoveries()
 
     # ---- per-kernel times of the sampled frames (HIP events on the launch stream) --------
     prof = {}
@@ -402,6 +408,9 @@ def main():
         for name, n in c.profile_frames().items():
             frames_of[name] = frames_of.get(name, 0) + n
     kernels = {name: {"avg_us": round(1e3 * ms / n, 2), "launches": n} for name, (ms, n) in prof.items()}
+    encoder = 2 if args.fused else 1 if "sat_walk_kernel" in kernels else 0
+    per_rank = sharding.gather_run(my_elapsed, B, device=dev if args.backend == "nccl" else None,
+                                   encoder=encoder, recoveries=recoveries)
     for name, k in kernels.items():  # a batched call's launch covers several frames
         fpl = frames_of.get(name, k["launches"]) / k["launches"]
         if fpl != 1:
@@ -461,6 +470,10 @@ def main():
         # whole path: SURVEY 8(d)'s figure for the two calls; fused, the table and its re-read are
         # not algorithmic work any more: frame in + reduced frame out
         path_bytes = (frame_bytes + 4 * rw * rh) if args.fused else enc_bytes + smp_bytes
+        per_frame_traffic = [pmc.get(name, {}).get(size_key) if isinstance(pmc.get(name), dict) else None
+                             for name in kernels if name in alg]
+        path_traffic = (int(sum(per_frame_traffic))
+                        if per_frame_traffic and all(t is not None for t in per_frame_traffic) else None)
         line = {
             "metric": "Mpixels/s (SAT+log-rectilinear warp), 8K equirect frames",
             "value": round(value, 1),
@@ -490,18 +503,22 @@ def main():
                        # which encoder the encode calls took: the read-once strip walker needs
                        # enough frames per call to fill the device, below that (e.g. 8 frames per
                        # rank with --global-batch 64 on 8 GPUs) the three-kernel encoder runs
-                       "encoder": ("fused (emit mode)" if args.fused else
-                                   "read-once (sat_walk_kernel)" if "sat_walk_kernel" in kernels
-                                   else "three kernels (reduce, carry, write)"),
+                       "encoder": sharding.ENCODERS[encoder],
                        "parallelism": f"frames sharded x{world}"},
             "roofline": roof,
             "roofline_kernels": roofline_kernels,
             "path_hbm_frac": round(path_bytes * (total_px / (w * h)) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+            # measured HBM-side bytes of one frame's pass over the path (sum of the kernels' PMC
+            # traffic, profiles/pmc_traffic.json) next to the algorithmic bytes path_hbm_frac uses
+            "path_traffic": path_traffic,
+            "path_algorithmic_bytes": int(path_bytes),
+            "handoff_recoveries": recoveries,
             "kernels": kernels,
         }
-        if world > 1:  # a straggler is visible: every rank's frames and ms per step
-            line["per_rank"] = [{"rank": r, "frames": n, "ms_per_step": round(1e3 * t / args.steps, 4)}
-                                for r, n, t in per_rank]
+        if world > 1:  # a straggler is visible: every rank's frames, ms per step and encoder
+            line["per_rank"] = [{"rank": r, "frames": n, "ms_per_step": round(1e3 * t / args.steps, 4),
+                                 "encoder": sharding.ENCODERS[e], "handoff_recoveries": rc}
+                                for r, n, t, e, rc in per_rank]
         if world == 1 and not args.fused and fpc > 1 and not args.no_variants:
             # The reference's own call shape on the same frames, outside the timed region: one
             # EncodeFrameGPU + one SampleFrameRectGPU per frame (src/video_server.cc:300,336)

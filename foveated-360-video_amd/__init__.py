@@ -144,6 +144,7 @@ _SIGNATURES = {
     "f360_ctx_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "f360_ctx_profile_frames": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "f360_debug_walk_stats": (c_int, [c_void_p, c_void_p, c_int]),
+    "f360_debug_walk_recoveries": (c_int, [c_void_p, POINTER(ctypes.c_uint)]),
     "f360_debug_gn_fast_sweep": (c_int, [c_void_p, c_int, ctypes.c_ulonglong, c_void_p, c_void_p]),
     "f360_debug_gnomonic_worklist": (c_int, [c_void_p, c_void_p]),
     "f360_ctx_profile_reset": (c_int, [c_void_p]),
@@ -286,6 +287,13 @@ class Context:
         if n < 0:
             _check(n)
         return out[:n]
+
+    def debug_walk_recoveries(self) -> int:
+        """Strips of read-once encoder launches that gave up waiting for their hand-off and
+        finished alone (exactly) since the last call (f360_debug_walk_recoveries)."""
+        c = ctypes.c_uint(0)
+        _check(lib().f360_debug_walk_recoveries(self._h, byref(c)))
+        return c.value
 
     def debug_gn_fast_sweep(self, kind: int, n: int = 1 << 30):
         """(largest |fast - double| seen, bound the guard assumes) of the gnomonic remap's float

@@ -180,6 +180,8 @@ struct f360_ctx {
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
   int opt_interp_staged = 1;   // "interp.staged": the un-warp computes the vertical lerps once per reduced column (wave-private LDS) instead of per output pixel
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
+  int opt_walk_spin = 0;       // "debug.walk_spin": polls a strip's hand-off wait may take before it finishes alone; 0 = 65536
+  int opt_walk_mute = 0;       // "debug.walk_mute": test only -- unit (value - 1) of every read-once launch publishes no hand-off, so its right neighbour times out; 0 = none
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
   int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   int opt_xcd_bands = 1;       // "is.xcd_bands": the point samplers give each XCD a band of output rows instead of every eighth workgroup: 0 never, 1 where it pays (log-rectilinear sampler, sources of 64 MB and more), 2 always

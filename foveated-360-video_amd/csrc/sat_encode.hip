@@ -161,7 +161,9 @@ struct EncodeArgs {
   int walk_units, walk_nbatches;
   struct WalkState *walk;
   unsigned long long *walk_chain;  // [unit][batch][24] {tag:40 | row prefix:24}
-  uint32_t *walk_err;              // host-visible: a hand-off wait ran into its bound
+  uint32_t *walk_err;              // host-visible: strips that gave up waiting and finished alone
+  uint32_t walk_spin;              // polls a hand-off wait may take before the strip goes it alone
+  int walk_mute;                   // test only ("debug.walk_mute"): this unit publishes nothing; -1
   unsigned long long *walk_stats;  // debug.ablate bit 8: per unit {start, end, slow polls, spins}
 };
 // (a kernel argument of its own: inside EncodeArgs the arrays keep the compiler from taking
@@ -796,9 +798,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
 // Forward progress: workgroups draw a ticket (atomic counter) and unit = ticket order, frames
 // major, strips left to right.  A strip only ever waits for the unit one ticket position before
 // it, whose workgroup drew its ticket earlier, i.e. is resident and running; strip 0 of a frame
-// waits for nobody.  Every wait is bounded (kWalkSpinLimit polls); a wave that runs into the
-// bound raises *walk_err (host-mapped, checked by f360_sync) and stops waiting, so the grid
-// always drains.  The state words live in device memory and are advanced by the launch itself
+// waits for nobody.  Every wait is bounded (a.walk_spin polls, a tenth of a second), and a strip
+// whose wait runs into the bound does not guess: it leaves the hand-off chain and finishes its
+// rows alone, computing the row sums of everything to its left from the source pixels itself
+// (slow -- strip s reads s strips per batch -- and exact), publishes correct prefixes for its
+// right neighbour as before, and counts itself in *walk_err (host-mapped;
+// f360_debug_walk_recoveries).  So the grid always drains AND the tables are always right: a
+// timeout costs time, never a result.  The state words live in device memory and are advanced by the launch itself
 // (the last wave to retire zeroes the ticket and bumps the serial), so nothing per launch
 // comes from the host: a captured launch replays correctly.
 struct WalkState {
@@ -812,7 +818,7 @@ constexpr int kWalkFrames = 64;              // frames per launch
 #endif
 constexpr int kWalkWaves = F360_WALK_WAVES;  // strip owners (consecutive units) per workgroup
 constexpr int kWalkLanes = 3 * kRowUnroll;   // granules per batch: 8 rows x 3 channels
-constexpr uint32_t kWalkSpinLimit = 1u << 20;
+constexpr uint32_t kWalkSpinDefault = 1u << 16;  // ~2 us per poll under load
 constexpr unsigned long long kWalkTagMask = (1ull << 40) - 1;
 
 struct WalkBatch {
@@ -837,9 +843,9 @@ __device__ __forceinline__ void walk_store_granule(unsigned long long *p, unsign
 // full wait, so the compiler's count of the pixel loads in flight is the fast path's.
 __device__ __forceinline__ unsigned long long walk_repoll(const unsigned long long *p,
                                                           unsigned long long tag, int lane,
-                                                          uint32_t &spun) {
+                                                          uint32_t limit, uint32_t &spun) {
   unsigned long long g = 0;
-  for (uint32_t spins = 0; spins < kWalkSpinLimit; ++spins) {
+  for (uint32_t spins = 0; spins < limit; ++spins) {
     ++spun;
     __builtin_amdgcn_s_sleep(4);
     asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
@@ -871,6 +877,48 @@ __device__ __forceinline__ void walk_load_batch(const EncodeArgs &a, const Encod
   reduce_load_batch<SRC>(a, fr, b, y, x0, y_last);
 }
 
+// The same batch for a strip that finishes alone (left_of_me): every load an asm of its own with
+// its own full wait, like walk_repoll's -- a load the compiler can see inside the row loop makes
+// it drain the prefetched batches at the loop head (the ISA guard found exactly that).
+__device__ __forceinline__ uint4 walk_alone_load16(const void *p) {
+  uint4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t walk_alone_load4(const void *p) {
+  uint32_t v;
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t walk_alone_load2(const void *p) {
+  uint32_t v;
+  asm volatile("global_load_ushort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int SRC>
+__device__ __forceinline__ void walk_alone_load_batch(const EncodeArgs &a, const EncodeFrame &fr,
+                                                      RowBatch<SRC> &b, int y, int x0,
+                                                      int y_last) {
+  const int xc = min(x0, a.width - kLanePx);
+  if constexpr (SRC >= kSrcYuvSwsC) {  // load_yuv_batch
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r)
+      b.y4[r] = walk_alone_load4(fr.y + (size_t)min(y + r, y_last) * a.yuv.y_linesize + xc);
+#pragma unroll
+    for (int r = 0; r < kRowUnroll / 2; ++r) {
+      const size_t crow = (size_t)min((y >> 1) + r, y_last >> 1);
+      const uint32_t u = walk_alone_load2(fr.u + crow * a.yuv.u_linesize + (xc >> 1));
+      const uint32_t v = walk_alone_load2(fr.v + crow * a.yuv.v_linesize + (xc >> 1));
+      b.uv[r] = u | (v << 16);
+    }
+  } else {  // reduce_load_batch<kSrcRgb0>
+    static_assert(SRC == kSrcRgb0, "the strip walker reads RGB0 or planar sources");
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r)
+      b.raw[r] = walk_alone_load16(fr.src + (size_t)xc * 4 + (size_t)min(y + r, y_last) * a.linesize);
+  }
+}
+
 template <int SRC, int DEPTH>
 __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeArgs a,
                                                                        const WalkBatch wb) {
@@ -897,8 +945,9 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
     fr.u = wb.u[f];
     fr.v = wb.v[f];
     const int x0 = strip * kStripPx + lane * kLanePx;
-    const bool pub = strip + 1 < a.nstrips;
-    bool need = strip > 0 && !(a.ablate & 64);   // timing experiment: nobody waits
+    const bool pub = strip + 1 < a.nstrips && unit != a.walk_mute;
+    const bool need = strip > 0 && !(a.ablate & 64);   // timing experiment: nobody waits
+    bool alone = false;  // a hand-off wait timed out: the rest of the strip without the chain
     const bool no_stores = a.ablate & 128;       // timing experiment: the table is not written
     const unsigned long long tag = serial & kWalkTagMask;
     const int nb = a.walk_nbatches;
@@ -919,10 +968,10 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
     const unsigned long long t_start = (a.ablate & 256) ? __builtin_amdgcn_s_memrealtime() : 0;
     const unsigned long long c_start = (a.ablate & 256) ? __builtin_amdgcn_s_memtime() : 0;
 
-    auto walk_batch = [&](const RowBatch<SRC> &raw, unsigned long long g, int t) {
-      const int y = t * kRowUnroll;
-      // --- the strip's own sums of the 8 rows: lane totals, wave scans (kept), row totals
-      uint32_t inc_rg[kRowUnroll], inc_b[kRowUnroll];
+    // --- a batch in three steps.  scan: the strip's own sums of the 8 rows -- lane totals, wave
+    // scans (kept for the row step), row totals in lanes 3r + c of the returned register
+    auto scan_batch = [&](const RowBatch<SRC> &raw, uint32_t (&inc_rg)[kRowUnroll],
+                          uint32_t (&inc_b)[kRowUnroll]) -> uint32_t {
       uint32_t tot = 0;  // lane 3r + c: this strip's sum of row y + r, channel c
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r) {
@@ -942,24 +991,18 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
         walk_writelane(tot, s_rg >> 16, 3 * r + 1);
         walk_writelane(tot, s_b, 3 * r + 2);
       }
-      // --- hand-off: running row prefixes in from the left, out to the right
-      uint32_t lin = 0;
-      if (need) {
-        if (!__all((g >> 24) == tag || lane >= kWalkLanes)) {
-          ++slow_polls;
-          g = walk_repoll(in + (size_t)t * kWalkLanes, tag, lane, spun);
-          if (!__all((g >> 24) == tag || lane >= kWalkLanes)) {  // gave up: say so, stop waiting
-            if (lane == 0)
-              __hip_atomic_store(a.walk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            need = false;
-          }
-        }
-        lin = (uint32_t)g & 0xffffffu;
-      }
+      return tot;
+    };
+    // publish: running row prefixes out to the right (lin: those that came in from the left)
+    auto publish = [&](int t, uint32_t lin, uint32_t tot) {
       if (pub && lane < kWalkLanes)
         walk_store_granule(out + (size_t)t * kWalkLanes,
                            (tag << 24) | (unsigned long long)((lin + tot) & 0xffffffu));
-      // --- the table rows (sat_write_kernel's row step with the scans already done)
+    };
+    // write: the table rows (sat_write_kernel's row step with the scans already done)
+    auto write_batch = [&](const RowBatch<SRC> &raw, const uint32_t (&inc_rg)[kRowUnroll],
+                           const uint32_t (&inc_b)[kRowUnroll], uint32_t lin, int t) {
+      const int y = t * kRowUnroll;
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r) {
         if (y + r > y_last) break;
@@ -1000,6 +1043,44 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
             global_store_b128_uncounted_nt(row + base + off, q[k]);
         }
       }
+    };
+    // The sums of rows [8t, 8t + 8) over all strips to the left, recomputed from the source with
+    // the very scan the neighbours use (lane 3r + c, like a granule's payload): what a strip
+    // whose hand-off did not come takes instead.  Slow (strip s reads s strips) and exact.
+    auto left_of_me = [&](int t) -> uint32_t {
+      uint32_t lin = 0;
+      for (int s = 0; s < strip; ++s) {
+        RowBatch<SRC> left;
+        uint32_t sc_rg[kRowUnroll], sc_b[kRowUnroll];
+        walk_alone_load_batch<SRC>(a, fr, left, t * kRowUnroll, s * kStripPx + lane * kLanePx,
+                                   y_last);
+        lin += scan_batch(left, sc_rg, sc_b);
+      }
+      return lin & 0xffffffu;
+    };
+    // One batch.  A wait for the left neighbour that runs into its bound (it cannot, short of a
+    // hung or descheduled neighbour) takes the strip off the hand-off chain for the rest of its
+    // rows: nothing is guessed, what is stored and what is published to the right are the values
+    // the chain would have delivered.
+    auto walk_batch = [&](const RowBatch<SRC> &raw, unsigned long long g, int t) {
+      uint32_t inc_rg[kRowUnroll], inc_b[kRowUnroll];
+      const uint32_t tot = scan_batch(raw, inc_rg, inc_b);
+      uint32_t lin = 0;
+      if (need) {
+        if (!alone && !__all((g >> 24) == tag || lane >= kWalkLanes)) {
+          ++slow_polls;
+          g = walk_repoll(in + (size_t)t * kWalkLanes, tag, lane, a.walk_spin, spun);
+          if (!__all((g >> 24) == tag || lane >= kWalkLanes)) {
+            alone = true;
+            if (lane == 0)
+              __hip_atomic_fetch_add(a.walk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        lin = alone ? left_of_me(t) : (uint32_t)g & 0xffffffu;
+      }
+      // out to the right BEFORE the heavy part: the chain advances at hand-off latency
+      publish(t, lin, tot);
+      write_batch(raw, inc_rg, inc_b, lin, t);
     };
 
     // DEPTH batches of 8 rows rotate through static buffers, DEPTH - 1 of them in flight.  The
@@ -1337,6 +1418,19 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   max_frames = std::min(max_frames, kWalkFrames);
   const int nlaunch = (count + max_frames - 1) / max_frames;
   const int per_launch = (count + nlaunch - 1) / nlaunch;
+  // Everything below that allocates, clears or synchronises is illegal while the stream is
+  // being captured into a hipGraph, and a captured launch keeps the hand-off buffer's address:
+  // warm up eagerly with the largest geometry and frame count first.
+  const size_t gran_bytes = (size_t)per_launch * nstrips * nb * kWalkLanes * 8;
+  const size_t chain_bytes = gran_bytes + (size_t)per_launch * nstrips * 32;
+  if (!p.walk_state.p || !p.walk_err_host || chain_bytes > p.walk_chain.bytes) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    F360_HIP_TRY(hipStreamIsCapturing(ctx->stream, &cap));
+    F360_REQUIRE(cap == hipStreamCaptureStatusNone,
+                 "f360_sat_encode_batch: the read-once encoder must allocate its hand-off buffers "
+                 "(%zu bytes) but the stream is being captured; run the same call once before "
+                 "the capture", chain_bytes);
+  }
   // state words: zero ticket / done, serial 1; the launches advance them
   if (!p.walk_state.p) {
     int st = p.walk_state.reserve(64);
@@ -1357,8 +1451,6 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   }
   // granules: zeroed when (re)allocated -- a tag is never 0 -- and never again
   // (+ 32 bytes per unit behind the granules: the debug statistics of debug.ablate bit 8)
-  const size_t gran_bytes = (size_t)per_launch * nstrips * nb * kWalkLanes * 8;
-  const size_t chain_bytes = gran_bytes + (size_t)per_launch * nstrips * 32;
   if (chain_bytes > p.walk_chain.bytes) {
     if (p.walk_chain.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
     int st = p.walk_chain.reserve(chain_bytes);
@@ -1382,6 +1474,8 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   a.walk = p.walk_state.as<WalkState>();
   a.walk_chain = p.walk_chain.as<unsigned long long>();
   a.walk_err = p.walk_err_dev;
+  a.walk_spin = ctx->opt_walk_spin > 0 ? (uint32_t)ctx->opt_walk_spin : kWalkSpinDefault;
+  a.walk_mute = ctx->opt_walk_mute - 1;
   a.walk_stats = reinterpret_cast<unsigned long long *>(p.walk_chain.as<uint8_t>() + gran_bytes);
   p.walk_stats_units = per_launch * nstrips;
   p.walk_stats_offset = gran_bytes;
@@ -1435,6 +1529,21 @@ extern "C" int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int
   F360_HIP_TRY(hipMemcpy(out, p.walk_chain.as<uint8_t>() + p.walk_stats_offset, (size_t)n * 32,
                          hipMemcpyDeviceToHost));
   return n;
+}
+
+// Strips of read-once launches that gave up waiting for their hand-off and finished alone (the
+// tables are right either way) since the last call of this function; blocks until the stream
+// has drained.
+extern "C" int f360_debug_walk_recoveries(f360_ctx *ctx, unsigned *count_out) {
+  F360_REQUIRE(ctx && count_out, "f360_debug_walk_recoveries: bad argument");
+  F360_BIND_DEVICE(ctx);
+  *count_out = 0;
+  f360::SatEncodePlan &p = ctx->enc;
+  if (!p.walk_err_host) return F360_OK;
+  F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *count_out = *p.walk_err_host;
+  *p.walk_err_host = 0;
+  return F360_OK;
 }
 
 extern "C" int f360_sat_encode(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev,

@@ -36,15 +36,22 @@ def reduce_run(elapsed_s: float, pixels: float, device=None):
     return float(t.item()), float(p.item())
 
 
-def gather_run(elapsed_s: float, frames: int, device=None):
-    """[(rank, frames, elapsed)] of every rank, on every rank (one all_gather of two doubles):
-    the benchmark prints it as `per_rank` so a straggler is visible.  Identity when not
-    distributed."""
+ENCODERS = ("three kernels (reduce, carry, write)", "read-once (sat_walk_kernel)",
+            "fused (emit mode)")
+
+
+def gather_run(elapsed_s: float, frames: int, device=None, encoder: int = 0, recoveries: int = 0):
+    """[(rank, frames, elapsed, encoder, recoveries)] of every rank, on every rank (one
+    all_gather of four doubles): the benchmark prints it as `per_rank`, so a straggler -- and a
+    rank whose encode calls fell back to the three-kernel encoder (`encoder`: index into
+    ENCODERS) or whose strip hand-offs timed out -- is visible.  Identity when not distributed."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return [(0, int(frames), float(elapsed_s))]
-    mine = torch.tensor([float(frames), elapsed_s], dtype=torch.float64, device=device)
+        return [(0, int(frames), float(elapsed_s), int(encoder), int(recoveries))]
+    mine = torch.tensor([float(frames), elapsed_s, float(encoder), float(recoveries)],
+                        dtype=torch.float64, device=device)
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
-    return [(r, int(t[0].item()), float(t[1].item())) for r, t in enumerate(out)]
+    return [(r, int(t[0].item()), float(t[1].item()), int(t[2].item()), int(t[3].item()))
+            for r, t in enumerate(out)]

@@ -365,6 +365,11 @@ int f360_ctx_profile_reset(f360_ctx *ctx);
  * that took the slow path, polls spent in them (4 x 64-bit words per unit, launch order).
  * Returns the number of units written (<= max_units), or a negative status. */
 int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int max_units);
+/* Strips of the read-once encoder whose wait for a hand-off ran into its bound ("debug.walk_spin"
+ * polls, about a tenth of a second) since the last call of this function.  Such a strip finishes
+ * alone -- it recomputes the row sums to its left from the source -- so the tables are exact
+ * either way; a non-zero count only says that time was lost.  Blocks until the stream is idle. */
+int f360_debug_walk_recoveries(f360_ctx *ctx, unsigned *count_out);
 /* Test entries for the index-guarded gnomonic remap (csrc/gn_fast_math.h, option
  * "gnomonic.guard").  _sweep: the largest absolute error of a fast float core against double
  * precision over a device-side sweep -- kind 0: asin over every float in [-1, 1] (n ignored);

@@ -84,6 +84,13 @@ def loops(ins):
     return [ins[lo:hi + 1] for lo, hi in inner]
 
 
+def all_loops(ins):
+    """Instruction slices of EVERY loop (backward branch .. its target), outer ones included."""
+    index = {a: i for i, (a, _, _) in enumerate(ins)}
+    return [ins[index[tgt]:i + 1] for i, (a, _, tgt) in enumerate(ins)
+            if tgt is not None and tgt <= a and tgt in index]
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     strict = "--strict" in sys.argv[1:]
@@ -147,14 +154,26 @@ def main():
                     polls = [t for t in texts if t.startswith("global_load_dwordx2")]
                     if len([t for t in polls if " sc1" in t]) < 2:
                         errors.append(f"{name}: hand-off polls must be sc1 loads")
-                    # between the first and the last table store the only full drains allowed
-                    # are the slow path's (each directly behind its own sc1 poll load)
-                    st = nts
-                    if st:
-                        body = texts[st[0]:st[-1] + 1]
+                    # the steady-state loop = the smallest loop that holds a batch's 24 table
+                    # stores AND the hand-off polls (the loop a strip finishes alone in after a
+                    # timed-out hand-off has the stores but no poll: it may drain as it likes).
+                    # Its only full drains are the slow paths', each directly behind its own
+                    # load in one asm statement: the re-poll of a hand-off (sc1) and the source
+                    # loads of a strip that finishes alone after a timed-out hand-off.
+                    cand = [[t for _, t, _ in lp] for lp in all_loops(ins)]
+                    cand = [lt for lt in cand
+                            if sum(t.startswith("global_store_dwordx4") and " nt" in t for t in lt) >= 24
+                            and any(t.startswith("global_load_dwordx2") and " sc1" in t for t in lt)]
+                    if not cand:
+                        perf.append(f"{name}: no steady-state loop (24 nt table stores + sc1 polls) found")
+                    else:
+                        body = min(cand, key=len)
+                        # (a wait at the loop head, before the iteration has issued anything, is
+                        # the wait for the oldest batch in flight whatever its immediate says)
+                        first_vmem = next(i for i, t in enumerate(body) if t.startswith("global_"))
                         bad = [i for i, t in enumerate(body) if t.startswith("s_waitcnt vmcnt(0)")
-                               and not (i > 0 and body[i - 1].startswith("global_load_dwordx2")
-                                        and " sc1" in body[i - 1])]
+                               and i > first_vmem
+                               and not body[i - 1].startswith("global_load_")]
                         if bad:
                             perf.append(f"{name}: {len(bad)} s_waitcnt vmcnt(0) on the fast path "
                                         f"of the row loop")

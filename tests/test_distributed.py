@@ -37,8 +37,9 @@ def _worker(rank, world, port, total_frames, out_dir):
         ob.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, grid, 0.5, 0.5)
         digests[g] = ob.fnv1a64(red)
     elapsed, pixels = sharding.reduce_run(1.0 + rank, float(len(digests) * w * h))
-    per_rank = sharding.gather_run(1.0 + rank, len(digests))  # what bench.py prints as per_rank
-    assert per_rank == [(r, len(sharding.shard_range(total_frames, world, r)), 1.0 + r)
+    # what bench.py prints as per_rank (rank 1 pretends its encoder fell back to three kernels)
+    per_rank = sharding.gather_run(1.0 + rank, len(digests), encoder=1 - rank, recoveries=rank)
+    assert per_rank == [(r, len(sharding.shard_range(total_frames, world, r)), 1.0 + r, 1 - r, r)
                         for r in range(world)], per_rank
     np.save(os.path.join(out_dir, f"rank{rank}.npy"),
             np.array([[g, d & 0xFFFFFFFF, d >> 32] for g, d in digests.items()] +

@@ -183,6 +183,98 @@ def test_walk_encode_from_planes(f360, walk_ctx, oracle, model, w, h, pad, n):
     assert bad == []
 
 
+def _planes_batch_and_check(f360, ctx, oracle, w, h, n, model=1, seed=77):
+    rng = np.random.default_rng(seed)
+    cw = w // 2
+    planes = [(rng.integers(0, 256, (h, w), dtype=np.uint8),
+               rng.integers(0, 256, (h // 2, cw), dtype=np.uint8),
+               rng.integers(0, 256, (h // 2, cw), dtype=np.uint8)) for _ in range(n)]
+    dev = [tuple(ctx.upload(p) for p in pl) for pl in planes]
+    sats = [ctx.malloc(w * h * 12) for _ in range(n)]
+    for s in sats:
+        s.fill(0xEE)
+    ctx.set_option("yuv.model", model)
+    f360.SATEncoder(ctx).EncodeFramesYUV420PGPU(
+        [s.ptr for s in sats], [(a.ptr, b.ptr, c.ptr) for (a, b, c) in dev], w, cw, cw, w, h)
+    bad = []
+    for k in range(n):
+        y, u, v = planes[k]
+        want = oracle.sat_encode(oracle.yuv420p_to_rgb0(y, u, v, w, h, model), w, h, 4 * w)
+        if not np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want):
+            bad.append(k)
+    for b in sats + [p for t in dev for p in t]:
+        b.free()
+    return bad
+
+
+def test_a_missing_hand_off_costs_time_not_a_result(f360, oracle):
+    """The failure path of the hand-off chain, driven for real.  "debug.walk_mute" makes one unit
+    publish nothing and "debug.walk_spin" shortens the bound of a wait from ~0.1 s to a few
+    polls: the right neighbour's wait times out, the strip leaves the chain, recomputes the row
+    sums to its left from the source for the rest of its rows and publishes correct prefixes
+    itself.  The grid drains, every table is the oracle's bit for bit, the recovery is counted,
+    and the next call on the same context (state words re-armed by the launch itself) is clean."""
+    with f360.Context(0) as ctx:
+        ctx.set_option("sat.walk", 1)
+        assert ctx.debug_walk_recoveries() == 0
+        for mute_unit, (w, h, n) in [(1, (1336, 203, 3)),      # strip 1 of frame 0 of 6 strips
+                                     (9, (1024, 64, 6)),       # strip 1 of frame 2 of 4 strips
+                                     (4, (2048, 50, 70))]:     # two launches: once in each
+            ctx.set_option("debug.walk_spin", 48)
+            ctx.set_option("debug.walk_mute", mute_unit + 1)
+            assert _encode_batch_and_check(f360, ctx, oracle, w, h, n, seed=31 * mute_unit) == []
+            ctx.finish()   # reports nothing: the tables are right
+            assert ctx.debug_walk_recoveries() >= 1, (mute_unit, w, h, n)
+            # planar sources recover through the same path (conversion in registers)
+            ctx.set_option("debug.walk_mute", 2)   # strip 1 of frame 0 of 5 strips
+            for model in (0, 1):
+                assert _planes_batch_and_check(f360, ctx, oracle, 1028, 22, 5, model) == []
+                assert ctx.debug_walk_recoveries() >= 1
+            # without the fault and with the shipped bound: exact, and nothing to recover
+            ctx.set_option("debug.walk_mute", 0)
+            ctx.set_option("debug.walk_spin", 0)
+            assert _encode_batch_and_check(f360, ctx, oracle, w, h, n, seed=5) == []
+            assert ctx.debug_walk_recoveries() == 0
+        # every wait one poll long: strips drop off the chain all over the frame, at any batch
+        ctx.set_option("debug.walk_spin", 1)
+        assert _encode_batch_and_check(f360, ctx, oracle, 2304, 256, 24, seed=8) == []
+        assert _planes_batch_and_check(f360, ctx, oracle, 1920, 1080, 2) == []
+        many = ctx.debug_walk_recoveries()
+        ctx.set_option("debug.walk_spin", 0)
+        assert _encode_batch_and_check(f360, ctx, oracle, 2304, 256, 24, seed=9) == []
+        assert ctx.debug_walk_recoveries() == 0
+        print(f"recoveries with one-poll waits: {many}")
+
+
+def test_walker_refuses_to_allocate_under_stream_capture(f360, oracle):
+    """The first read-once call on a context allocates its hand-off buffers (and a larger call
+    re-allocates them): illegal while the stream is being captured, so it is refused with a
+    message instead of breaking the capture; after an eager warm-up the capture works
+    (test_walker_launch_replays_from_a_hip_graph)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test without a GPU")
+    dev = torch.device("cuda", 0)
+    w, h, n = 1280, 72, 4
+    frames = torch.zeros((n, h, 4 * w), dtype=torch.uint8, device=dev)
+    sats = [torch.zeros((h, w, 3), dtype=torch.int32, device=dev) for _ in range(n)]
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        ctx = f360.Context(0, stream=side.cuda_stream)
+        ctx.set_option("sat.walk", 1)
+        enc = f360.SATEncoder(ctx)
+        g = torch.cuda.CUDAGraph()
+        refused = False
+        with torch.cuda.graph(g, stream=side):
+            try:
+                enc.EncodeFramesGPU([s.data_ptr() for s in sats],
+                                    [frames[k].data_ptr() for k in range(n)], w, h, 4 * w)
+            except f360.F360Error as e:
+                refused = "captured" in str(e)
+        assert refused
+    ctx.close()
+
+
 def test_config4_batch_through_the_automatic_choice(f360, oracle):
     """BASELINE config 4 the way bench.py runs it: 32 of its frames (31 LCG frames + the all-255
     frame whose sums wrap mod 2^32) resident, one EncodeFramesGPU call -- 960 strips: the
