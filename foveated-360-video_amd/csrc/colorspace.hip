@@ -291,6 +291,185 @@ __global__ __launch_bounds__(256) void rgb0_to_yuv420p_kernel(
   }
 }
 
+// The same conversion for whole frames, walking down ("yuv.r2y_rows" chroma rows per wave): the
+// four source rows of a chroma sample overlap the next sample's by two, so the kernel above reads
+// every source row twice and evaluates its chroma twice.  Here a lane owns four chroma columns
+// (eight pixels, 32 bytes of a source row) and keeps the 15-bit chroma of the window's rows
+// 2c - 1 .. 2c + 2 in registers: per chroma row it loads two new source rows -- requested one
+// chroma row ahead --, evaluates their luma and chroma once, and slides the window by two.
+// Stores are issued from inline asm (non-temporal, invisible to the compiler's vmcnt
+// bookkeeping: a store in the loop would otherwise turn every wait for a prefetched row into a
+// full drain, sat_encode.hip "toolchain findings").  The borders use the window as it is: row
+// -1 and row `height` are loaded clamped and carry tap 0, the other taps are the folded ones.
+__device__ __forceinline__ void r2y_store8(uint8_t *base, uint32_t off, uint32_t a, uint32_t b) {
+  typedef uint32_t u32x2_r __attribute__((ext_vector_type(2)));
+  const u32x2_r v{a, b};
+  asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void r2y_store4(uint8_t *base, uint32_t off, uint32_t a) {
+  asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(off), "v"(a), "s"(base) : "memory");
+}
+
+// The row walker is bound by its vector ALU, so its arithmetic is the formulas above reduced to
+// what the hardware does at full rate -- identical results, proven here, checked by the parity
+// tests for both models:
+//  * products through the 24-bit multiplier (coefficients < 2^15, channel sums < 2^10, 15-bit
+//    chroma times taps <= 2048: every operand fits);
+//  * luma: clip8((min(2 Y14, 32767) + 64) >> 7) with Y14 = S >> 9 is min((S + 16384) >> 15, 255):
+//    (2a + 64) >> 7 = (a + 32) >> 6 and floor((floor(S / 512) + 32) / 64) = floor((S + 16384) /
+//    32768); once 2 Y14 exceeds 32767 both forms give 255; S > 0, so no lower clamp;
+//  * chroma: U14 <= (BU * 510 + (256 << 15) + 512) >> 10 = 15360, so min(2 U14, 32767) never
+//    clamps (V likewise: RV = BU), and U14 >= 0.
+__device__ __forceinline__ uint32_t r2y_luma8(const Rgb2YuvConsts &k, uint32_t px) {
+  const int r = px & 0xff, g = (px >> 8) & 0xff, b = (px >> 16) & 0xff;
+  const int s = __mul24(k.ry, r) + __mul24(k.gy, g) + __mul24(k.by, b) + ((32 << 14) + (1 << 8) + 16384);
+  return min((uint32_t)s >> 15, 255u);
+}
+__device__ __forceinline__ int2 r2y_chroma15(const Rgb2YuvConsts &k, uint32_t p0, uint32_t p1) {
+  const uint32_t rb = (p0 & 0x00ff00ffu) + (p1 & 0x00ff00ffu);  // R sum | B sum << 16
+  const int r = rb & 0xffff, b = rb >> 16;
+  const int g = (int)((p0 >> 8) & 0xff) + (int)((p1 >> 8) & 0xff);
+  const int su = __mul24(k.ru, r) + __mul24(k.gu, g) + __mul24(k.bu, b) + ((256 << 15) + (1 << 9));
+  const int sv = __mul24(k.rv, r) + __mul24(k.gv, g) + __mul24(k.bv, b) + ((256 << 15) + (1 << 9));
+  return make_int2((su >> 10) << 1, (sv >> 10) << 1);
+}
+
+struct R2yRow {
+  uint32_t px[8];
+};
+__device__ __forceinline__ R2yRow r2y_load(const uint8_t *src, int src_linesize, int y,
+                                           uint32_t xoff) {
+  typedef uint32_t u32x4_r __attribute__((ext_vector_type(4)));
+  const uint8_t *row = src + (size_t)y * src_linesize + xoff;
+  const u32x4_r a = *reinterpret_cast<const u32x4_r *>(row);
+  const u32x4_r b = *reinterpret_cast<const u32x4_r *>(row + 16);
+  return R2yRow{{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}};
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void rgb0_to_yuv420p_walk_kernel(
+    uint8_t *__restrict__ y_dst, uint8_t *__restrict__ u_dst, uint8_t *__restrict__ v_dst,
+    int y_linesize, int u_linesize, int v_linesize, const uint8_t *__restrict__ src,
+    int src_linesize, int width, int height, const Rgb2YuvConsts k, int rows_per_wave,
+    int nstrips) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int strip = wave % nstrips;
+  const int cy0 = (wave / nstrips) * rows_per_wave;
+  const int cw = width >> 1, ch = height >> 1;
+  if (cy0 >= ch) return;
+  const int cy1 = min(cy0 + rows_per_wave, ch);
+  const int c_own = (strip * 64 + lane) * 4;  // first chroma column of the lane
+  const bool writes = c_own < cw;             // width % 8 == 0: a lane is in or out as a whole
+  const int c0 = min(c_own, cw - 4);          // idle lanes read in bounds and store nothing
+  const uint32_t xoff = (uint32_t)c0 * 8u;
+  const int y_last = height - 1;
+
+  int wu[4][4], wv[4][4];  // window [slot][pair]: chroma of source rows 2cy - 1 .. 2cy + 2
+  // one source row: its luma (stored if the row is this wave's) and its chroma into a slot
+  auto take_row = [&](const R2yRow &r, int y, int slot, bool own_luma) {
+    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t yv = r2y_luma8(k, r.px[q]);
+      if (q < 4) w0 |= yv << (8 * q);
+      else w1 |= yv << (8 * (q - 4));
+    }
+    if (own_luma && writes)
+      r2y_store8(y_dst, (uint32_t)y * (uint32_t)y_linesize + (uint32_t)c0 * 2u, w0, w1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int2 c = r2y_chroma15(k, r.px[2 * q], r.px[2 * q + 1]);
+      wu[slot][q] = c.x;
+      wv[slot][q] = c.y;
+    }
+  };
+  // prologue: rows 2cy0 - 1 (clamped; never this wave's luma) and 2cy0
+  {
+    const R2yRow a = r2y_load(src, src_linesize, max(2 * cy0 - 1, 0), xoff);
+    const R2yRow b = r2y_load(src, src_linesize, 2 * cy0, xoff);
+    take_row(a, 0, 0, false);
+    take_row(b, 2 * cy0, 1, true);
+  }
+  R2yRow na = r2y_load(src, src_linesize, min(2 * cy0 + 1, y_last), xoff);
+  R2yRow nb = r2y_load(src, src_linesize, min(2 * cy0 + 2, y_last), xoff);
+  for (int cy = cy0; cy < cy1; ++cy) {
+    const R2yRow ra = na, rb = nb;
+    // the next chroma row's two source rows, unconditionally (clamped addresses)
+    na = r2y_load(src, src_linesize, min(2 * cy + 3, y_last), xoff);
+    nb = r2y_load(src, src_linesize, min(2 * cy + 4, y_last), xoff);
+    take_row(ra, 2 * cy + 1, 2, true);
+    // row 2cy + 2 is luma row 0 of chroma row cy + 1: this wave's unless that is the next run's
+    take_row(rb, 2 * cy + 2, 3, cy + 1 < cy1);
+    // taps on the window's rows: interior 512 1536 1536 512; folded at the frame's borders
+    // (first chroma row: 0 2048 1536 512 -- row -1 was loaded clamped and carries no weight --,
+    // last: 512 1536 2048 0).  x86 builds: every chroma row but the last through the truncating
+    // 16-bit multiply (pmulhw: (c * tap) >> 16 per tap, paddw wraps; the sum of the terms wraps
+    // to the same value).  Interior rows take the taps as constants: (c * 512) >> 16 = c >> 7,
+    // (c * 1536) >> 16 = (3 c) >> 7.
+    uint32_t ub = 0, vb = 0;
+    if (cy > 0 && cy < ch - 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (MODEL == 1) {
+          const int au = 5 + (wu[0][q] >> 7) + ((3 * wu[1][q]) >> 7) + ((3 * wu[2][q]) >> 7) +
+                         (wu[3][q] >> 7);
+          const int av = 5 + (wv[0][q] >> 7) + ((3 * wv[1][q]) >> 7) + ((3 * wv[2][q]) >> 7) +
+                         (wv[3][q] >> 7);
+          ub |= shift_clip8<3>((int)(int16_t)au) << (8 * q);
+          vb |= shift_clip8<3>((int)(int16_t)av) << (8 * q);
+        } else {
+          const int au = (64 << 12) + 512 * (wu[0][q] + wu[3][q]) + 1536 * (wu[1][q] + wu[2][q]);
+          const int av = (64 << 12) + 512 * (wv[0][q] + wv[3][q]) + 1536 * (wv[1][q] + wv[2][q]);
+          ub |= shift_clip8<19>(au) << (8 * q);
+          vb |= shift_clip8<19>(av) << (8 * q);
+        }
+      }
+    } else {
+      int t0 = 512, t1 = 1536, t2 = 1536, t3 = 512;
+      if (cy == 0) {
+        t0 = 0;
+        t1 = 2048;
+      }
+      if (cy == ch - 1) {
+        t2 = 2048;
+        t3 = 0;
+      }
+      const bool mmx = MODEL == 1 && cy < ch - 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (mmx) {
+          const int au = 5 + (__mul24(wu[0][q], t0) >> 16) + (__mul24(wu[1][q], t1) >> 16) +
+                         (__mul24(wu[2][q], t2) >> 16) + (__mul24(wu[3][q], t3) >> 16);
+          const int av = 5 + (__mul24(wv[0][q], t0) >> 16) + (__mul24(wv[1][q], t1) >> 16) +
+                         (__mul24(wv[2][q], t2) >> 16) + (__mul24(wv[3][q], t3) >> 16);
+          ub |= shift_clip8<3>((int)(int16_t)au) << (8 * q);
+          vb |= shift_clip8<3>((int)(int16_t)av) << (8 * q);
+        } else {
+          const int au = (64 << 12) + __mul24(wu[0][q], t0) + __mul24(wu[1][q], t1) +
+                         __mul24(wu[2][q], t2) + __mul24(wu[3][q], t3);
+          const int av = (64 << 12) + __mul24(wv[0][q], t0) + __mul24(wv[1][q], t1) +
+                         __mul24(wv[2][q], t2) + __mul24(wv[3][q], t3);
+          ub |= shift_clip8<19>(au) << (8 * q);
+          vb |= shift_clip8<19>(av) << (8 * q);
+        }
+      }
+    }
+    if (writes) {
+      r2y_store4(u_dst, (uint32_t)cy * (uint32_t)u_linesize + (uint32_t)c0, ub);
+      r2y_store4(v_dst, (uint32_t)cy * (uint32_t)v_linesize + (uint32_t)c0, vb);
+    }
+    // slide by two source rows
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wu[0][q] = wu[2][q];
+      wv[0][q] = wv[2][q];
+      wu[1][q] = wu[3][q];
+      wv[1][q] = wv[3][q];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int f360_rgb0_to_yuv420p(f360_ctx *ctx, uint8_t *y_dev, uint8_t *u_dev, uint8_t *v_dev,
@@ -323,7 +502,27 @@ extern "C" int f360_rgb0_to_yuv420p(f360_ctx *ctx, uint8_t *y_dev, uint8_t *u_de
   hipLaunchKernelGGL((rgb0_to_yuv420p_kernel<M, P>), dim3(((cw + P - 1) / P + 63) / 64, (ch + 3) / 4), \
                      dim3(256), 0, ctx->stream, y_dev, u_dev, v_dev, y_linesize, u_linesize,    \
                      v_linesize, src_dev, src_linesize, width, height, k)
-  if (vec) {
+  // the row-walking kernel: vector layout, 32-bit store offsets and enough waves.
+  // "yuv.r2y_rows" = 0 (default): the longest runs of 16 / 8 / 4 chroma rows that still give
+  // 1536 waves, 4 down to 512 waves (8K: 16 rows, 42.2 -> 34.4 us; the 4272x2144 reduced frame:
+  // 4 rows, 16.4 -> 14.0 us), below that the kernel with one chroma row per thread; n > 0:
+  // always, with runs of n; -1: never
+  const int nstrips = (cw / 4 + 63) / 64;
+  auto waves_with = [&](int r) { return (long)nstrips * ((ch + r - 1) / r); };
+  int rpw = ctx->opt_r2y_rows;
+  if (rpw == 0) rpw = waves_with(16) >= 1536 ? 16 : waves_with(8) >= 1536 ? 8 : waves_with(4) >= 512 ? 4 : -1;
+  const long waves = rpw > 0 ? waves_with(rpw) : 0;
+  if (vec && rpw > 0 && (size_t)y_linesize * height < ((size_t)1 << 32)) {
+    const dim3 wgrid((unsigned)((waves + 3) / 4));
+    if (x86)
+      hipLaunchKernelGGL(rgb0_to_yuv420p_walk_kernel<1>, wgrid, dim3(256), 0, ctx->stream, y_dev,
+                         u_dev, v_dev, y_linesize, u_linesize, v_linesize, src_dev, src_linesize,
+                         width, height, k, rpw, nstrips);
+    else
+      hipLaunchKernelGGL(rgb0_to_yuv420p_walk_kernel<0>, wgrid, dim3(256), 0, ctx->stream, y_dev,
+                         u_dev, v_dev, y_linesize, u_linesize, v_linesize, src_dev, src_linesize,
+                         width, height, k, rpw, nstrips);
+  } else if (vec) {
     if (x86) F360_R2Y(1, 4);
     else F360_R2Y(0, 4);
   } else {

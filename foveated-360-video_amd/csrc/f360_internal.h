@@ -180,6 +180,7 @@ struct f360_ctx {
   int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
   int opt_interp_staged = 1;   // "interp.staged": the un-warp computes the vertical lerps once per reduced column (wave-private LDS) instead of per output pixel
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
+  int opt_r2y_rows = 0;        // "yuv.r2y_rows": chroma rows a wave of the RGB0 -> yuv420p converter walks down; 0 = by frame size (16 / 8 / 4, small frames: the kernel with one chroma row per thread), -1 = always that kernel
   int opt_walk_spin = 0;       // "debug.walk_spin": polls a strip's hand-off wait may take before it finishes alone; 0 = 65536
   int opt_walk_mute = 0;       // "debug.walk_mute": test only -- unit (value - 1) of every read-once launch publishes no hand-off, so its right neighbour times out; 0 = none
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results

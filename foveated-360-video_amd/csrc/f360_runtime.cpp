@@ -279,6 +279,7 @@ static const OptionSlot kOptions[] = {
     {"interp.staged", &f360_ctx::opt_interp_staged},
     {"sample.reverse", &f360_ctx::opt_sample_reverse},
     {"yuv.model", &f360_ctx::opt_yuv_model},
+    {"yuv.r2y_rows", &f360_ctx::opt_r2y_rows},
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},
@@ -300,6 +301,8 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
       if (s.field == &f360_ctx::opt_yuv_model)
         F360_REQUIRE(value == 0 || value == 1,
                      "yuv.model must be 0 (libswscale C tables) or 1 (libswscale x86): %d", value);
+      if (s.field == &f360_ctx::opt_r2y_rows)
+        F360_REQUIRE(value >= -1 && value <= 4096, "yuv.r2y_rows out of range -1..4096: %d", value);
       if (s.field == &f360_ctx::opt_walk_rows)
         F360_REQUIRE(value >= 1 && value <= 4096, "sample.rows out of range: %d", value);
       if (s.field == &f360_ctx::opt_stream_rows)

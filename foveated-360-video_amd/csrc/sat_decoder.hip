@@ -466,114 +466,137 @@ __global__ __launch_bounds__(256) void decode_kernel(
   }
 }
 
-// The same for 4-byte pixels and a width that is a multiple of 4.  A wave owns a 256-pixel
-// strip (4 pixels = 48 table bytes per lane) and walks kDecodeRows rows with the previous
-// row in registers, so a table row is read once (plus one halo row per chunk) instead of
-// twice; the left neighbours arrive by DPP.  Texels outside the frame count as zero, which
+// The same for 4-byte pixels and a width that is a multiple of 4, as a row streamer.  A wave
+// owns a 256-pixel strip (4 pixels = 48 table bytes per lane) and walks kDecodeRows rows with the
+// previous row in registers, so a table row is read once (plus one halo row per run); the left
+// neighbours arrive by DPP.  Round 4: what a row needs -- its 3 KiB table segment, the 1 KiB of
+// the destination whose 4th bytes must survive, the texel left of the strip -- goes memory ->
+// LDS directly (global_load_lds: contiguous 1 KiB requests instead of three 16-byte loads per
+// lane at a 48-byte stride, no staging registers) into a ring of kDecodeSlots slots, three rows
+// ahead of the row being decoded; the wait is a counted vmcnt and the stores are issued from
+// inline asm (sample_stream.h has the reasons).  Texels outside the frame count as zero, which
 // turns the kernel's four cases (:20-57) into one expression in modular u32 arithmetic.  The
 // fourth byte of every pixel is preserved by a 16-byte read-modify-write owned by one lane.
-constexpr int kDecodeRows = 16;
-constexpr int kDecodeBatch = 4;  // rows whose loads are issued together
-
-typedef uint32_t u32x4_d __attribute__((ext_vector_type(4)));
+// (runs of 16 / 64 / 128 rows and rings of 3 / 6 slots measure the same 110-114 us at 8K: the
+// kernel moves 354 MB of table + 118 MB of old pixels + 118 MB of new ones at the 5.3 TB/s this
+// device sustains on mixed traffic, profiles/round4_streaming_siblings.txt)
+constexpr int kDecodeRows = 32;
+constexpr int kDecodeSlots = 4;
+constexpr int kDecodeSlotBytes = 3072 + 1024 + 16;  // table segment | old pixels | left texel
+constexpr int kDecodeLoadsPerRow = 5;
 
 struct DecodeRow {
   uint32_t t[12];  // 4 texels x 3 channels
   uint32_t l[3];   // the texel left of the first one
 };
 
-__device__ __forceinline__ DecodeRow decode_load_row(const uint32_t *__restrict__ sat,
-                                                     size_t row_dw, int y, int x0, int lane,
-                                                     bool has_left_strip) {
-  DecodeRow r;
-  const uint32_t *p = sat + (size_t)y * row_dw + (size_t)3 * x0;
-  const u32x4_d *q = reinterpret_cast<const u32x4_d *>(p);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const u32x4_d v = q[k];
-    r.t[4 * k + 0] = v.x;
-    r.t[4 * k + 1] = v.y;
-    r.t[4 * k + 2] = v.z;
-    r.t[4 * k + 3] = v.w;
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) r.l[c] = 0;
-  if (lane == 0 && has_left_strip) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) r.l[c] = p[c - 3];
-  }
-  return r;
-}
-
 __global__ __launch_bounds__(256) void decode_strip_kernel(
     uint8_t *__restrict__ dst, int dst_linesize, const uint32_t *__restrict__ sat, int width,
     int height, int strips) {
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) uint8_t ring[4][kDecodeSlots * kDecodeSlotBytes];
+  const int wslot = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4) + wslot);
   const int lane = threadIdx.x & 63;
   const int strip = wave % strips;
   const int y0 = (wave / strips) * kDecodeRows;
   if (y0 >= height) return;
   const int x_own = strip * 256 + lane * 4;
   const bool writes = x_own < width;
-  const int x0 = min(x_own, width - 4);  // idle lanes read in bounds and store nothing
-  const size_t row_dw = (size_t)3 * width;
-  const bool has_left_strip = strip > 0;
+  const bool has_left_strip = strip > 0, has_up = y0 > 0;
+  const int n = min(kDecodeRows, height - y0) + 1;  // streamed rows: the row above, then mine
+  // per-lane source offsets inside a table row / a destination row; chunks past the row's end
+  // (the last strip of a width that is not a multiple of 256) re-read its last chunk
+  const uint32_t row_bytes = (uint32_t)width * 12u;
+  const uint32_t seg = (uint32_t)strip * 3072u;
+  const uint32_t last_chunk = row_bytes - 16u;
+  uint32_t tab_off[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tab_off[k] = min(seg + (uint32_t)(k * 64 + lane) * 16u, last_chunk);
+  const uint32_t old_off = (uint32_t)min(x_own, width - 4) * 4u;
+  const uint32_t left_off = has_left_strip ? seg - 12u + (uint32_t)min(lane, 2) * 4u : 0u;
+  const char *tab = reinterpret_cast<const char *>(sat);
+  uint8_t *my = &ring[wslot][0];
+  const uint32_t my_lds = (uint32_t)reinterpret_cast<uintptr_t>(my);
 
+  auto issue = [&](int slot, int i) {  // streamed row i = frame row y0 - 1 + i (clamped)
+    const int y = min(max(y0 - 1 + i, 0), height - 1);
+    const char *row = tab + (size_t)y * row_bytes;
+    uint8_t *d = my + slot * kDecodeSlotBytes;
+    __builtin_amdgcn_global_load_lds((ts_gptr)(row + tab_off[0]), (ts_lptr)d, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((ts_gptr)(row + tab_off[1]), (ts_lptr)(d + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((ts_gptr)(row + tab_off[2]), (ts_lptr)(d + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((ts_gptr)(dst + (size_t)y * dst_linesize + old_off),
+                                     (ts_lptr)(d + 3072), 16, 0, 0);
+    if (lane < 3)
+      __builtin_amdgcn_global_load_lds((ts_gptr)(row + left_off), (ts_lptr)(d + 4096), 4, 0, 0);
+  };
+  constexpr int D = kDecodeSlots - 1;
+#pragma unroll
+  for (int k = 0; k < D; ++k) issue(k, min(k, n - 1));
   DecodeRow up;
-  if (y0 > 0) {
-    up = decode_load_row(sat, row_dw, y0 - 1, x0, lane, has_left_strip);
-  } else {
+  int slot = 0, slot_pf = D;
+  for (int i = 0; i < n; ++i) {
+    issue(slot_pf, min(i + D, n - 1));  // unconditional: every row is exactly 5 operations
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * kDecodeLoadsPerRow) : "memory");
+    const uint32_t base = my_lds + (uint32_t)slot * kDecodeSlotBytes;
+    slot = slot + 1 == kDecodeSlots ? 0 : slot + 1;
+    slot_pf = slot_pf + 1 == kDecodeSlots ? 0 : slot_pf + 1;
+    u32x4_t q0, q1, q2, old;
+    u32x2_t l01;
+    uint32_t l2;
+    asm volatile(
+        "ds_read_b128 %0, %6\n\t"
+        "ds_read_b128 %1, %6 offset:16\n\t"
+        "ds_read_b128 %2, %6 offset:32\n\t"
+        "ds_read_b128 %3, %7\n\t"
+        "ds_read_b64 %4, %8\n\t"
+        "ds_read_b32 %5, %8 offset:8\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(old), "=&v"(l01), "=&v"(l2)
+        : "v"(base + (uint32_t)lane * 48u), "v"(base + 3072u + (uint32_t)lane * 16u),
+          "v"(base + 4096u)
+        : "memory");
+    DecodeRow c;
+    c.t[0] = q0.x; c.t[1] = q0.y; c.t[2] = q0.z; c.t[3] = q0.w;
+    c.t[4] = q1.x; c.t[5] = q1.y; c.t[6] = q1.z; c.t[7] = q1.w;
+    c.t[8] = q2.x; c.t[9] = q2.y; c.t[10] = q2.z; c.t[11] = q2.w;
+    c.l[0] = has_left_strip ? l01.x : 0u;
+    c.l[1] = has_left_strip ? l01.y : 0u;
+    c.l[2] = has_left_strip ? l2 : 0u;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) up.t[k] = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) up.l[c] = 0;
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const uint32_t from_left = dpp_from_lane_below(up.t[9 + c]);
-    if (lane != 0) up.l[c] = from_left;
-  }
-
-  const int y_end = min(y0 + kDecodeRows, height);
-  for (int yb = y0; yb < y_end; yb += kDecodeBatch) {
-    DecodeRow cur[kDecodeBatch];
-    u32x4_d old[kDecodeBatch];
-#pragma unroll
-    for (int r = 0; r < kDecodeBatch; ++r) {
-      const int y = min(yb + r, height - 1);
-      cur[r] = decode_load_row(sat, row_dw, y, x0, lane, has_left_strip);
-      old[r] = *reinterpret_cast<const u32x4_d *>(dst + (size_t)y * dst_linesize +
-                                                  (size_t)x0 * 4);
+    for (int ch = 0; ch < 3; ++ch) {
+      const uint32_t from_left = dpp_from_lane_below(c.t[9 + ch]);
+      if (lane != 0) c.l[ch] = from_left;
     }
+    if (i == 0) {  // the row above my first one: no output; above the frame it counts as zero
+      if (!has_up) {
 #pragma unroll
-    for (int r = 0; r < kDecodeBatch; ++r) {
-      if (yb + r >= y_end) break;
-      DecodeRow &c = cur[r];
+        for (int k = 0; k < 12; ++k) c.t[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c.l[k] = 0;
+      }
+      up = c;
+      continue;
+    }
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t v[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        const uint32_t from_left = dpp_from_lane_below(c.t[9 + ch]);
-        if (lane != 0) c.l[ch] = from_left;
+        const uint32_t left = k ? c.t[3 * (k - 1) + ch] : c.l[ch];
+        const uint32_t up_left = k ? up.t[3 * (k - 1) + ch] : up.l[ch];
+        v[ch] = min(c.t[3 * k + ch] - up.t[3 * k + ch] + up_left - left, 255u);
       }
-      uint32_t px[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t v[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const uint32_t left = k ? c.t[3 * (k - 1) + ch] : c.l[ch];
-          const uint32_t up_left = k ? up.t[3 * (k - 1) + ch] : up.l[ch];
-          v[ch] = min(c.t[3 * k + ch] - up.t[3 * k + ch] + up_left - left, 255u);
-        }
-        const uint32_t keep = k == 0 ? old[r].x : k == 1 ? old[r].y : k == 2 ? old[r].z : old[r].w;
-        px[k] = (keep & 0xff000000u) | v[0] | (v[1] << 8) | (v[2] << 16);
-      }
-      if (writes)
-        F360_STREAM_STORE(
-            reinterpret_cast<u32x4_d *>(dst + (size_t)(yb + r) * dst_linesize + (size_t)x0 * 4),
-            (u32x4_d{px[0], px[1], px[2], px[3]}));
-      up = c;
+      px[k] = (old[k] & 0xff000000u) | v[0] | (v[1] << 8) | (v[2] << 16);
     }
+    if (writes)
+      store_b128_uncounted(dst, (uint32_t)(y0 - 1 + i) * (uint32_t)dst_linesize + (uint32_t)x_own * 4u,
+                           u32x4_t{px[0], px[1], px[2], px[3]});
+    up = c;
   }
+  // nothing may still be landing in this wave's LDS when the workgroup's allocation is reused
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------
@@ -1411,6 +1434,8 @@ int f360_satdec_decode(f360_sat_decoder *dec, uint8_t *target_dev,
                "f360_satdec_decode: bad geometry");
   const bool strip_path =
       width % 4 == 0 && target_linesize % 16 == 0 && target_linesize / width == 4 &&
+      (size_t)target_linesize * height < ((size_t)1 << 32) &&
+      (size_t)width * 12 * height < ((size_t)1 << 40) &&
       (reinterpret_cast<uintptr_t>(target_dev) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(sat_dev) & 15) == 0;
   if (strip_path) {

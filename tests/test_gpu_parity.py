@@ -219,9 +219,12 @@ def test_encode_sample_pipeline_full_size(f360, gpu_ctx, oracle, golden_digests,
 
 
 # --------------------------------------------------------------- decode / interpolate (rect)
-@pytest.mark.parametrize("w,h", [(320, 96), (260, 37), (1024, 50), (322, 19), (8, 3)])
+@pytest.mark.parametrize("w,h", [(320, 96), (260, 37), (1024, 50), (322, 19), (8, 3), (4, 1), (256, 33),
+                                 (516, 65), (1920, 1080), (2560, 31)])
 def test_decode_matches_oracle_and_inverts(f360, gpu_ctx, oracle, w, h):
-    # widths that are multiples of 4 take the strip walker, the others the per-pixel kernel
+    # widths that are multiples of 4 take the row streamer (runs of 32 rows per wave: heights
+    # around its run length, strips that end 4 pixels into the last one), the others the
+    # per-pixel kernel
     frame = oracle.lcg_frame(w, h, 4)
     sat_h = oracle.sat_encode(frame, w, h, 4 * w)
     dec = f360.SATDecoder(gpu_ctx)
@@ -1062,13 +1065,21 @@ def test_fused_foveation_from_yuv420p(f360, gpu_ctx, oracle, w, h):
 
 
 @pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("rows", [-1, 0, 1, 3, 8, 64])
 @pytest.mark.parametrize("w,h,spad,pads,off", [(64, 32, 0, (0, 0, 0), 0), (4272, 2144, 0, (0, 0, 0), 0),
                                                 (72, 16, 16, (8, 4, 12), 0), (70, 10, 4, (1, 3, 5), 0),
-                                                (64, 8, 0, (0, 0, 0), 4), (2, 8, 0, (0, 0, 0), 0)])
-def test_rgb0_to_yuv420p_matches_oracle(f360, gpu_ctx, oracle, model, w, h, spad, pads, off):
+                                                (64, 8, 0, (0, 0, 0), 4), (2, 8, 0, (0, 0, 0), 0),
+                                                (520, 38, 0, (0, 0, 0), 0), (1032, 8, 16, (8, 4, 4), 0)])
+def test_rgb0_to_yuv420p_matches_oracle(f360, gpu_ctx, oracle, model, rows, w, h, spad, pads, off):
     """The output-side colour step (VideoEncoder's sws_scale, video_encoder.cc:380-395) on the
     device: both libswscale models, the 8-pixel vector kernel and the any-even-width kernel
-    (odd multiples of two, padded rows, unaligned base), bytes outside the planes untouched."""
+    (odd multiples of two, padded rows, unaligned base), bytes outside the planes untouched.
+    "yuv.r2y_rows": the row-walking kernel forced on with runs of 1 / 3 / 8 / 64 chroma rows
+    (run borders anywhere, the frame's first and last chroma row inside one run or alone),
+    the automatic choice (0), and never (-1)."""
+    if rows > 0 and (w, h) == (4272, 2144) and rows not in (8,):
+        pytest.skip("the large frame once per kernel is enough")
+    gpu_ctx.set_option("yuv.r2y_rows", rows)
     rng = np.random.default_rng(17)
     src_h = rng.integers(0, 256, (h, 4 * w + spad), dtype=np.uint8)
     want = oracle.rgb0_to_yuv420p(src_h, w, h, model, pads=pads)
@@ -1089,6 +1100,7 @@ def test_rgb0_to_yuv420p_matches_oracle(f360, gpu_ctx, oracle, model, w, h, spad
         buf.free()
     src.free()
     gpu_ctx.set_option("yuv.model", 1)
+    gpu_ctx.set_option("yuv.r2y_rows", 0)
 
 
 def test_rgb0_to_yuv420p_argument_checks(f360, gpu_ctx):
