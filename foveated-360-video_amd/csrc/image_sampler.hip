@@ -660,6 +660,8 @@ int f360_is_sample_logpolar(f360_image_sampler *is, uint8_t *target_dev,
                "f360_is_sample_logpolar: need >= 3 bytes per pixel");
   F360_REQUIRE(!bad_centre(center_x) && !bad_centre(center_y),
                "f360_is_sample_logpolar: gaze centre out of range");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}),
+               "f360_is_sample_logpolar: a dimension exceeds 65536");
   const dim3 grid((target_width + 63) / 64, (target_height + 4 * kPointRows - 1) / (4 * kPointRows));
   hipLaunchKernelGGL(is_sample_logpolar_kernel, grid, dim3(256), 0, is->ctx->stream,
                      target_dev, target_width, target_height, target_linesize,
