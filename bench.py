@@ -131,9 +131,9 @@ def launch_plan(gpus, batch, global_batch):
 def encoder_plan(width, frames_per_call, opts):
     """Which encoder an EncodeFramesGPU call of `frames_per_call` frames takes (the library's
     rule, sat_encode.hip walk_wanted): the read-once strip walker needs frames x strips >=
-    sat.walk_units (960: 32 frames at 8K) to fill the device, below that the three kernels run."""
+    sat.walk_units (690: 23 frames at 8K) to outrun them, below that the three kernels run."""
     o = dict(kv.split("=") for kv in opts)
-    walk, units = int(o.get("sat.walk", -1)), int(o.get("sat.walk_units", 960))
+    walk, units = int(o.get("sat.walk", -1)), int(o.get("sat.walk_units", 690))
     if frames_per_call <= 1 or walk == 0:
         return "three kernels (reduce, carry, write)"
     if walk == 1 or frames_per_call * ((width + 255) // 256) >= units:
@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--frames-per-call", type=int, default=64,
                     help="two-call path: N frames per EncodeFramesGPU / EncodeFramesYUV420PGPU call, then one "
                          "SampleFramesRectGPU call for their N tables.  With enough frames to fill the "
-                         "device (960 strips: 32 frames at 8K) the encode call takes the read-once "
+                         "device (690 strips: 23 frames at 8K) the encode call takes the read-once "
                          "encoder (sat_walk_kernel, launches of about 1024 strips), below that the "
                          "three-kernel one; the sampler shares launches of 16.  1 = EncodeFrameGPU + SampleFrameRectGPU "
                          "per frame, the reference's own loop (also reported: "

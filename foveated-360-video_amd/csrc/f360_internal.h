@@ -173,7 +173,7 @@ struct f360_ctx {
   int opt_sample_fpl = 16;     // "sample.fpl": frames per launch of f360_satdec_sample_rect_frames (1..64)
   int opt_batch_mb = 180;      // "sat.batch_mb": source bytes (MB) a batched encoder launch may cover
   int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows
-  int opt_walk_units = 960;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder
+  int opt_walk_units = 690;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder (23 frames at 8K: a launch takes at least its 480 serial batches of ~3.5 us whatever its frame count, so below ~22 frames the three kernels' 101 us per frame win; profiles/round4_few_frames.txt)
   int opt_walk_frames = 0;     // "sat.walk_frames": most frames one read-once launch takes (1..64); 0 = about 1024 strip owners, one per SIMD
   int opt_walk_depth = 2;      // "sat.walk_depth": 8-row batches a strip owner rotates through (2 | 3), all but one in flight
   int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel

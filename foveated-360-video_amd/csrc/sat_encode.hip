@@ -1413,8 +1413,12 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   // launch on the same box: with two owners per SIMD the per-batch jitter that the hand-off
   // chain accumulates is five times larger), so a larger call runs as
   // several launches of about 1024 units, never fewer units than the call's own frames allow.
-  const int strips = (width + kStripPx - 1) / kStripPx;
-  int max_frames = ctx->opt_walk_frames > 0 ? ctx->opt_walk_frames : std::max(1024 / strips, 1);
+  // A launch must not exceed the device by a little: 35 frames (1050 units) take 3.8 ms -- the
+  // 26 units of the second round walk their 480 batches alone -- where 32 take 2.6; and a launch
+  // costs its serial chain (height / 8 batches of ~3.5 us: 1.7 ms at 8K) however few frames it
+  // holds, so 40 frames as one oversubscribed launch (4.3 ms) or as two of 20 (4.1 ms) are both
+  // no better than the three kernels (profiles/round4_few_frames.txt).
+  int max_frames = ctx->opt_walk_frames > 0 ? ctx->opt_walk_frames : std::max(1024 / nstrips, 1);
   max_frames = std::min(max_frames, kWalkFrames);
   const int nlaunch = (count + max_frames - 1) / max_frames;
   const int per_launch = (count + nlaunch - 1) / nlaunch;
