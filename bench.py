@@ -180,6 +180,8 @@ def main():
                          "three-kernel one; the sampler shares launches of 16.  1 = EncodeFrameGPU + SampleFrameRectGPU "
                          "per frame, the reference's own loop (also reported: "
                          "value_reference_call_shape)")
+    ap.add_argument("--one-alloc", action="store_true",
+                    help="A/B: carve the tables of a call from one device allocation")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (in-order streams) per GPU; frames go round-robin over them "
                          "(3 gives ~15%% more throughput; 1 keeps every kernel launch comparable with "
@@ -288,8 +290,12 @@ def main():
     # (several streams: frames go round-robin over the contexts one call pair at a time)
     fpc = 1 if args.fused else max(1, min(args.frames_per_call, B))
     # one set of tables per context: a call pair's tables live until its sample call has run
-    sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev)
-            for _ in range(len(ctxs) * fpc)]
+    if args.one_alloc:  # A/B: the tables carved from ONE allocation instead of one each
+        slab = torch.empty((len(ctxs) * fpc, h, w, 3), dtype=torch.int32, device=dev)
+        sats = [slab[k] for k in range(len(ctxs) * fpc)]
+    else:
+        sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev)
+                for _ in range(len(ctxs) * fpc)]
     reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
     gazes = [lissajous(g) for g in mine]
     if yuv:
