@@ -182,6 +182,15 @@ def main():
                          "value_reference_call_shape)")
     ap.add_argument("--one-alloc", action="store_true",
                     help="A/B: carve the tables of a call from one device allocation")
+    ap.add_argument("--table-pad", type=int, default=0,
+                    help="with --one-alloc: bytes between consecutive tables (multiple of 16)")
+    ap.add_argument("--table-pitch-mb", type=int, default=0,
+                    help="with --one-alloc: distance between consecutive tables in MiB")
+    ap.add_argument("--table-alloc-mb", type=int, default=0,
+                    help="A/B: one allocation of this many MiB per table")
+    ap.add_argument("--table-alloc-reverse", action="store_true")
+    ap.add_argument("--print-addresses", action="store_true",
+                    help="print the device addresses of the first tables and frames on stderr")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (in-order streams) per GPU; frames go round-robin over them "
                          "(3 gives ~15%% more throughput; 1 keeps every kernel launch comparable with "
@@ -290,9 +299,19 @@ def main():
     # (several streams: frames go round-robin over the contexts one call pair at a time)
     fpc = 1 if args.fused else max(1, min(args.frames_per_call, B))
     # one set of tables per context: a call pair's tables live until its sample call has run
-    if args.one_alloc:  # A/B: the tables carved from ONE allocation instead of one each
-        slab = torch.empty((len(ctxs) * fpc, h, w, 3), dtype=torch.int32, device=dev)
-        sats = [slab[k] for k in range(len(ctxs) * fpc)]
+    nt_, tb = len(ctxs) * fpc, 12 * w * h
+    if args.one_alloc:  # A/B: the tables carved from ONE allocation, --table-pad bytes apart
+        pitch = tb + args.table_pad
+        if args.table_pitch_mb:
+            pitch = args.table_pitch_mb << 20
+        slab = torch.empty((nt_ * pitch,), dtype=torch.uint8, device=dev)
+        sats = [slab[k * pitch:k * pitch + tb].view(torch.int32).view(h, w, 3) for k in range(nt_)]
+    elif args.table_alloc_mb:  # A/B: one allocation of this size per table
+        keep = [torch.empty((args.table_alloc_mb << 20,), dtype=torch.uint8, device=dev)
+                for _ in range(nt_)]
+        if args.table_alloc_reverse:
+            keep = keep[::-1]
+        sats = [k[:tb].view(torch.int32).view(h, w, 3) for k in keep]
     else:
         sats = [torch.empty((h, w, 3), dtype=torch.int32, device=dev)
                 for _ in range(len(ctxs) * fpc)]
@@ -305,6 +324,9 @@ def main():
         frame_ptr = [frames[k].data_ptr() for k in range(B)]
     red_ptr = [reds[k].data_ptr() for k in range(B)]
     sat_ptr = [s.data_ptr() for s in sats]
+    if args.print_addresses and rank == 0:
+        sys.stderr.write("tables " + " ".join(hex(p) for p in sat_ptr[:6]) + " deltas " +
+                         " ".join(hex(b - a) for a, b in zip(sat_ptr[:8], sat_ptr[1:9])) + "\n")
     torch.cuda.synchronize(dev)
 
     calls = [0]
