@@ -1,19 +1,16 @@
 #!/bin/bash
-# table placement against the read-once encoder: the default (one allocation per table, as large
-# as the table), one 512 MiB allocation per table, one slab.  One gpurun call.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 one() {
-  python bench.py --no-cpu-baseline --no-variants --steps 6 "$@" > gpurun_out/abo.json 2> gpurun_out/abo.err || { tail -3 gpurun_out/abo.err; return; }
+  python bench.py --no-cpu-baseline --no-variants "$@" > gpurun_out/abo.json 2> gpurun_out/abo.err || { tail -5 gpurun_out/abo.err; return; }
   python - "$*" <<PY
 import json, sys
 d = json.loads(open("gpurun_out/abo.json").read().strip().splitlines()[-1])
-print(sys.argv[1], d["value"], d["path_hbm_frac"], {k: round(v.get("avg_us_per_frame", v["avg_us"]), 1) for k, v in d["kernels"].items()})
+print(sys.argv[1], d["value"], d["path_hbm_frac"], {k: round(v.get("avg_us_per_frame", v["avg_us"]), 1) for k, v in d["kernels"].items()}, d["config"]["table_placement"])
 PY
 }
 for rep in 1 2 3; do
+  one --placement separate
   one
-  one --table-alloc-mb 512
-  one --table-alloc-mb 1024
-  one --one-alloc
+  one --placement slab
 done
