@@ -1,0 +1,109 @@
+// frontbench.hip -- the read-once encoder's WRITE pattern on its own (not part of the product):
+// NF tables of 7680 x 3840 x 12 bytes written at the same time, one wave per (table, 256-pixel
+// strip) walking down the rows -- 3 x 1 KiB stores per row, a full drain every 8 rows, like
+// sat_walk_kernel -- against where the tables lie: one allocation each, or carved from one
+// allocation at a given pitch.  profiles/round4_table_placement.txt has the encoder's own figures.
+//   hipcc --offload-arch=gfx950 -O3 tools/frontbench.hip -o tools/frontbench && tools/frontbench
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int W = 7680, H = 3840, NF = 32, STRIPS = W / 256;
+constexpr size_t ROW = (size_t)W * 12, TAB = ROW * H;
+struct Tabs {
+  uint8_t *p[NF];
+};
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// MODE 0: like the walker (drain every 8 rows); 1: never drain; 2: rows of a batch in reverse order;
+// 3: units interleaved so that neighbouring waves belong to DIFFERENT tables
+template <int MODE>
+__global__ __launch_bounds__(256) void write_fronts(const Tabs t, int nf, int rows, int skew = 0) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= nf * STRIPS) return;
+  int f, s;
+  if (MODE == 3) {
+    f = unit % nf;
+    s = unit / nf;
+  } else {
+    f = unit / STRIPS;
+    s = unit - f * STRIPS;
+  }
+  uint8_t *base = t.p[f] + (size_t)s * 3072 + (size_t)lane * 16;
+  const u32x4 v{(uint32_t)unit, 1u, 2u, 3u};
+  const int y_start = (f * skew) % rows & ~7;  // table f starts `skew` rows further down (wraps)
+  for (int yy = 0; yy < rows; yy += 8) {
+    int y = yy + y_start;
+    if (y >= rows) y -= rows;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int rr = MODE == 2 ? 7 - r : r;
+      uint8_t *row = base + (size_t)(y + rr) * ROW;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(row + k * 1024), "v"(v) : "memory");
+    }
+    if (MODE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+template <int MODE>
+static float run(const Tabs &t, int nf, const char *what, int skew = 0) {
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  float best = 1e30f, sum = 0;
+  const int reps = 6;
+  for (int r = 0; r < reps + 1; ++r) {
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(write_fronts<MODE>, dim3((nf * STRIPS + 3) / 4), dim3(256), 0, 0, t, nf, H, skew);
+    (void)hipEventRecord(b);
+    (void)hipEventSynchronize(b);
+    float ms;
+    (void)hipEventElapsedTime(&ms, a, b);
+    if (r == 0) continue;
+    best = ms < best ? ms : best;
+    sum += ms;
+  }
+  if (skew) printf("  [skew %4d rows]", skew);
+  printf("  %-46s mode %d: best %.1f us per table, mean %.1f  (%.2f TB/s)\n", what, MODE, best * 1e3f / nf,
+         sum / reps * 1e3f / nf, (double)TAB * nf / (best * 1e-3) / 1e12);
+  return best;
+}
+
+int main() {
+  // A: one allocation per table
+  Tabs sep;
+  for (int f = 0; f < NF; ++f) CK(hipMalloc(&sep.p[f], TAB));
+  printf("separate allocations, deltas:");
+  for (int f = 1; f < 4; ++f) printf(" %lld", (long long)(sep.p[f] - sep.p[f - 1]));
+  printf("\n");
+  run<0>(sep, NF, "one allocation per table");
+  run<1>(sep, NF, "one allocation per table");
+  run<3>(sep, NF, "one allocation per table");
+  for (int skew : {8, 40, 120}) run<0>(sep, NF, "one allocation per table", skew);
+  // B: one slab, several pitches
+  const size_t pitches[] = {TAB, (size_t)512 << 20, TAB + ((size_t)5 << 20), TAB + 92160, (size_t)1 << 30};
+  for (size_t pitch : pitches) {
+    uint8_t *slab;
+    CK(hipMalloc(&slab, pitch * NF));
+    Tabs t;
+    for (int f = 0; f < NF; ++f) t.p[f] = slab + (size_t)f * pitch;
+    char what[96];
+    snprintf(what, sizeof what, "one slab, pitch %zu (table + %lld)", pitch, (long long)(pitch - TAB));
+    run<0>(t, NF, what);
+    run<3>(t, NF, what);
+    for (int skew : {8, 16, 24, 40, 120, 1000}) run<0>(t, NF, what, skew);
+    CK(hipFree(slab));
+  }
+  // C: one 512 MiB allocation per table
+  Tabs big;
+  for (int f = 0; f < NF; ++f) CK(hipMalloc(&big.p[f], (size_t)512 << 20));
+  run<0>(big, NF, "one 512 MiB allocation per table");
+  // D: fewer tables at a time with the same number of waves?  16 tables, 30 strips: half the waves
+  run<0>(sep, 16, "one allocation per table, 16 tables");
+  return 0;
+}
