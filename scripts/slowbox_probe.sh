@@ -1,4 +1,5 @@
 #!/bin/bash
+# bench.py's placement calibration against fixed placements, alternating; one gpurun call
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 one() {
@@ -12,5 +13,4 @@ PY
 for rep in 1 2 3; do
   one --placement separate
   one
-  one --placement slab
 done
