@@ -1,16 +1,8 @@
 #!/bin/bash
-# bench.py's placement calibration against fixed placements, alternating; one gpurun call
+# what kind of box is this (one allocation per table fast or slow)?  then the write pattern alone
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
-one() {
-  python bench.py --no-cpu-baseline --no-variants "$@" > gpurun_out/abo.json 2> gpurun_out/abo.err || { tail -5 gpurun_out/abo.err; return; }
-  python - "$*" <<PY
-import json, sys
-d = json.loads(open("gpurun_out/abo.json").read().strip().splitlines()[-1])
-print(sys.argv[1], d["value"], d["path_hbm_frac"], {k: round(v.get("avg_us_per_frame", v["avg_us"]), 1) for k, v in d["kernels"].items()}, d["config"]["table_placement"])
-PY
-}
-for rep in 1 2 3; do
-  one --placement separate
-  one
-done
+python bench.py --no-cpu-baseline --no-variants --steps 6 --placement separate > gpurun_out/abo.json 2>/dev/null
+python -c "
+import json; d=json.loads(open('gpurun_out/abo.json').read().strip().splitlines()[-1]); print('separate placement:', d['value'], d['path_hbm_frac'], {k: round(v.get('avg_us_per_frame', v['avg_us']), 1) for k, v in d['kernels'].items()})"
+timeout -k 10 200 ./tools/frontbench | grep -v "skew"

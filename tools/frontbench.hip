@@ -18,7 +18,9 @@ struct Tabs {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 0: like the walker (drain every 8 rows); 1: never drain; 2: rows of a batch in reverse order;
-// 3: units interleaved so that neighbouring waves belong to DIFFERENT tables
+// 3: units interleaved so that neighbouring waves belong to DIFFERENT tables; 5: every wave stays
+// inside the first 16 rows of its table (1.4 MiB: one or two translation entries per table) and
+// writes them over and over -- the same bytes per wave, no new pages
 template <int MODE>
 __global__ __launch_bounds__(256) void write_fronts(const Tabs t, int nf, int rows, int skew = 0) {
   const int lane = threadIdx.x & 63;
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(256) void write_fronts(const Tabs t, int nf, int ro
   for (int yy = 0; yy < rows; yy += 8) {
     int y = yy + y_start;
     if (y >= rows) y -= rows;
+    if (MODE == 5) y &= 8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int rr = MODE == 2 ? 7 - r : r;
@@ -74,7 +77,30 @@ static float run(const Tabs &t, int nf, const char *what, int skew = 0) {
   return best;
 }
 
-int main() {
+int pool_scan() {
+  // ONE pool; tables carved at different base offsets and pitches inside it: the same physical
+  // backing throughout, so whatever differs is decided by the addresses alone
+  const size_t pool_bytes = (size_t)40 << 30;
+  uint8_t *pool;
+  CK(hipMalloc(&pool, pool_bytes));
+  printf("pool at %p\n", (void *)pool);
+  for (int rep = 0; rep < 2; ++rep)
+    for (size_t base_mib : {0, 2, 4, 6, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 3, 5, 100}) {
+      for (size_t extra_mib : {0, 5, 55}) {
+        const size_t pitch = TAB + (extra_mib << 20);
+        Tabs t;
+        for (int f = 0; f < NF; ++f) t.p[f] = pool + (base_mib << 20) + (size_t)f * pitch;
+        char what[96];
+        snprintf(what, sizeof what, "pool + %zu MiB, pitch table + %zu MiB", base_mib, extra_mib);
+        run<0>(t, NF, what);
+      }
+    }
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1 && argv[1][0] == 'p') return pool_scan();
+  const bool scan = argc > 1;
   // A: one allocation per table
   Tabs sep;
   for (int f = 0; f < NF; ++f) CK(hipMalloc(&sep.p[f], TAB));
@@ -85,8 +111,13 @@ int main() {
   run<1>(sep, NF, "one allocation per table");
   run<3>(sep, NF, "one allocation per table");
   for (int skew : {8, 40, 120}) run<0>(sep, NF, "one allocation per table", skew);
-  // B: one slab, several pitches
-  const size_t pitches[] = {TAB, (size_t)512 << 20, TAB + ((size_t)5 << 20), TAB + 92160, (size_t)1 << 30};
+  // B: one slab, several pitches (argv[1] = "scan": many)
+  std::vector<size_t> pitches = {TAB, (size_t)512 << 20, TAB + ((size_t)5 << 20), TAB + 92160, (size_t)1 << 30};
+  if (scan) {
+    pitches.clear();
+    for (int mib : {0, 1, 2, 3, 4, 5, 6, 7, 9, 11, 13, 17, 21, 27, 37, 53, 67, 101}) pitches.push_back(TAB + ((size_t)mib << 20));
+    for (int kib : {128, 256, 384, 640, 896, 1152}) pitches.push_back(TAB + ((size_t)kib << 10));
+  }
   for (size_t pitch : pitches) {
     uint8_t *slab;
     CK(hipMalloc(&slab, pitch * NF));
@@ -95,14 +126,23 @@ int main() {
     char what[96];
     snprintf(what, sizeof what, "one slab, pitch %zu (table + %lld)", pitch, (long long)(pitch - TAB));
     run<0>(t, NF, what);
-    run<3>(t, NF, what);
-    for (int skew : {8, 16, 24, 40, 120, 1000}) run<0>(t, NF, what, skew);
+    if (!scan) run<3>(t, NF, what);
     CK(hipFree(slab));
   }
   // C: one 512 MiB allocation per table
   Tabs big;
   for (int f = 0; f < NF; ++f) CK(hipMalloc(&big.p[f], (size_t)512 << 20));
   run<0>(big, NF, "one 512 MiB allocation per table");
+  run<5>(sep, NF, "one allocation per table, 16 rows over and over");
+  {
+    uint8_t *slab;
+    CK(hipMalloc(&slab, TAB * NF));
+    Tabs t;
+    for (int f = 0; f < NF; ++f) t.p[f] = slab + (size_t)f * TAB;
+    run<0>(t, NF, "one slab");
+    run<5>(t, NF, "one slab, 16 rows over and over");
+    CK(hipFree(slab));
+  }
   // D: fewer tables at a time with the same number of waves?  16 tables, 30 strips: half the waves
   run<0>(sep, 16, "one allocation per table, 16 tables");
   return 0;
