@@ -1,5 +1,7 @@
 #!/bin/bash
-# what kind of box is this (one allocation per table fast or slow)?  then the write pattern alone
+# Table placement against the read-once encoder (profiles/round4_table_placement.txt): the default
+# command with one allocation per table, then the write pattern alone (tools/frontbench: build it
+# first, see its header).  One gpurun call.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 python bench.py --no-cpu-baseline --no-variants --steps 6 --placement separate > gpurun_out/abo.json 2>/dev/null
