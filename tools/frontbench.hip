@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -77,6 +78,113 @@ static float run(const Tabs &t, int nf, const char *what, int skew = 0) {
   return best;
 }
 
+// One table written by 960 waves: wave (band, strip) walks 1/32 of the rows of its strip
+__global__ __launch_bounds__(256) void write_one(uint8_t *tab) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= NF * STRIPS) return;
+  const int band = unit / STRIPS, s = unit - band * STRIPS;
+  uint8_t *base = tab + (size_t)s * 3072 + (size_t)lane * 16;
+  const u32x4 v{(uint32_t)unit, 1u, 2u, 3u};
+  const int y0 = band * (H / NF);
+  for (int y = y0; y < y0 + H / NF; y += 8) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint8_t *row = base + (size_t)(y + r) * ROW;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(row + k * 1024), "v"(v) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+int per_bo_scan() {
+  // is the write rate a property of each buffer object?  96 tables, each timed alone (32 row bands
+  // x 30 strips in flight inside it), then 32 fronts over the 32 fastest and over the 32 slowest
+  const int N = 96;
+  std::vector<uint8_t *> bo(N);
+  std::vector<float> us(N);
+  for (int i = 0; i < N; ++i) CK(hipMalloc(&bo[i], TAB));
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  for (int i = 0; i < N; ++i) {
+    float best = 1e30f;
+    for (int r = 0; r < 5; ++r) {
+      (void)hipEventRecord(a);
+      hipLaunchKernelGGL(write_one, dim3(NF * STRIPS / 4), dim3(256), 0, 0, bo[i]);
+      (void)hipEventRecord(b);
+      (void)hipEventSynchronize(b);
+      float ms;
+      (void)hipEventElapsedTime(&ms, a, b);
+      if (r) best = ms < best ? ms : best;
+    }
+    us[i] = best * 1e3f;
+  }
+  std::vector<int> order(N);
+  for (int i = 0; i < N; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int x, int y) { return us[x] < us[y]; });
+  printf("per-table write alone, us (sorted):");
+  for (int i = 0; i < N; ++i) printf(" %.1f", us[order[i]]);
+  printf("\n");
+  Tabs fast, slow, mid;
+  for (int f = 0; f < NF; ++f) {
+    fast.p[f] = bo[order[f]];
+    slow.p[f] = bo[order[N - 1 - f]];
+    mid.p[f] = bo[f];
+  }
+  run<0>(fast, NF, "32 fronts over the 32 fastest tables");
+  run<0>(slow, NF, "32 fronts over the 32 slowest tables");
+  run<0>(mid, NF, "32 fronts over the first 32 allocated");
+  run<0>(fast, NF, "32 fronts over the 32 fastest tables (again)");
+  return 0;
+}
+
+// Tables backed through the virtual-memory API: `chunk` bytes per physical handle (0 = one handle
+// per table), all mapped into one reserved address range per table
+static int vmm_table(uint8_t **out, size_t chunk) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = 0;
+  size_t gran = 0;
+  CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+  if (chunk == 0) chunk = TAB;
+  chunk = (chunk + gran - 1) / gran * gran;
+  const size_t total = (TAB + chunk - 1) / chunk * chunk;
+  void *va = nullptr;
+  CK(hipMemAddressReserve(&va, total, 0, nullptr, 0));
+  for (size_t off = 0; off < total; off += chunk) {
+    hipMemGenericAllocationHandle_t h;
+    CK(hipMemCreate(&h, chunk, &prop, 0));
+    CK(hipMemMap((char *)va + off, chunk, 0, h, 0));
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  CK(hipMemSetAccess(va, total, &acc, 1));
+  *out = (uint8_t *)va;
+  return 0;
+}
+
+int vmm_scan() {
+  Tabs sep;
+  for (int f = 0; f < NF; ++f) CK(hipMalloc(&sep.p[f], TAB));
+  run<0>(sep, NF, "hipMalloc, one allocation per table");
+  for (size_t chunk : {(size_t)0, (size_t)2 << 20, (size_t)8 << 20, (size_t)16 << 20, (size_t)32 << 20, (size_t)32 << 20,
+                       (size_t)48 << 20, (size_t)64 << 20, (size_t)128 << 20}) {
+    Tabs t;
+    for (int f = 0; f < NF; ++f)
+      if (vmm_table(&t.p[f], chunk)) return 1;
+    char what[96];
+    snprintf(what, sizeof what, "hipMemCreate, %zu MiB per handle%s", chunk >> 20, chunk ? "" : " (one per table)");
+    run<0>(t, NF, what);
+  }
+  run<0>(sep, NF, "hipMalloc, one allocation per table (again)");
+  return 0;
+}
+
 int pool_scan() {
   // ONE pool; tables carved at different base offsets and pitches inside it: the same physical
   // backing throughout, so whatever differs is decided by the addresses alone
@@ -100,6 +208,8 @@ int pool_scan() {
 
 int main(int argc, char **argv) {
   if (argc > 1 && argv[1][0] == 'p') return pool_scan();
+  if (argc > 1 && argv[1][0] == 'b') return per_bo_scan();
+  if (argc > 1 && argv[1][0] == 'v') return vmm_scan();
   const bool scan = argc > 1;
   // A: one allocation per table
   Tabs sep;
