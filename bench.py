@@ -181,10 +181,11 @@ def main():
                          "per frame, the reference's own loop (also reported: "
                          "value_reference_call_shape)")
     ap.add_argument("--placement", default="auto",
-                    help="where the tables of a call lie: auto = time one encode call per "
-                         "candidate placements (up to eight) before the timed region and keep the fastest (read-once "
-                         "encoder only), separate = one allocation per table, slab = one for all, "
-                         "separateN = one N-MiB allocation per table")
+                    help="where the tables of a call lie: auto = the engine's allocator for batched "
+                         "calls (f360_sat_tables_alloc: draws groups of tables, times one launch into "
+                         "each, keeps the fastest; read-once encoder only), separate = one torch "
+                         "allocation per table, slab = one for all, separateN = one N-MiB allocation "
+                         "per table")
     ap.add_argument("--one-alloc", action="store_true",
                     help="A/B: carve the tables of a call from one device allocation")
     ap.add_argument("--table-pad", type=int, default=0,
@@ -335,50 +336,15 @@ def main():
         keep_tables, sats = alloc_tables(how, nt_)
         placement["chosen"] = how
     else:
-        # Calibrate once, outside the timed region, as a caller that owns its buffers can.  The
-        # tables one launch of the read-once encoder writes at the same time are a GROUP (32 at
-        # 8K); how a group happens to be backed decides the launch's time, and that differs from
-        # allocation to allocation (50-64 us per table for the write pattern alone,
-        # tools/frontbench).  So: draw groups -- every one allocated while all earlier ones are
-        # still held, so it is backed by other memory --, time one encode launch into each, keep
-        # the fastest ones the calls need, give the rest back.
-        strips = (w + 255) // 256
-        max_frames = max(1024 // strips, 1)
-        n_launch = -(-fpc // max_frames)
-        group = -(-fpc // n_launch)
-        need = n_launch * len(ctxs)
-        good_us = 81.0 * (w * h) / (7680.0 * 3840.0)
-        methods = ["separate", "slab", "separate", "separate512", "separate", "slab",
-                   "separate384", "separate"]
-        draws = []  # (us per frame, how, keep-alive, tables)
-        srcs = [frames[k].data_ptr() for k in range(min(group, B))]
-        for i in range(need + 6):
-            how = methods[i % len(methods)]
-            keep, tabs = alloc_tables(how, group)
-            ptrs = [t.data_ptr() for t in tabs[:len(srcs)]]
-            us = 0.0
-            for rep in range(2):  # the second call is the measurement (first: buffers, clocks)
-                ctxs[0].profile_reset()
-                ctxs[0].profile_arm(1)
-                encs[0].EncodeFramesGPU(ptrs, srcs, w, h, 4 * w)
-                ctxs[0].finish()
-                ms, n = ctxs[0].profile_read().get("sat_walk_kernel", (0.0, 0))
-                us = 1e3 * ms / max(len(srcs), 1)
-            ctxs[0].profile_reset()
-            draws.append((us, how, keep, tabs))
-            placement["tried"].append({"group": how, "walker_us_per_frame": round(us, 1)})
-            if sum(1 for d in draws if d[0] <= good_us) >= need:
-                break
-        draws.sort(key=lambda d: d[0])
-        chosen = draws[:need]
-        keep_tables = [d[2] for d in chosen]
-        sats = [t for d in chosen for t in d[3]]
-        placement["chosen"] = [{"group": d[1], "walker_us_per_frame": round(d[0], 1)} for d in chosen]
-        placement["group_frames"] = group
-        del draws, keep, tabs
-        torch.cuda.empty_cache()  # the losers' memory goes back to the driver
-        if len(ctxs) == 1 and n_launch * group != fpc:
-            sats = sats[:fpc]
+        # The engine's own allocator for the tables of batched calls (f360_sat_tables_alloc): it
+        # draws groups of the tables one launch writes at the same time (32 at 8K), each
+        # allocated while the earlier ones are still held, times one encode launch into each
+        # and keeps the fastest -- outside the timed region, once, as a caller of the
+        # reference allocates its cl::Buffers once (src/video_server.cc:225-232).
+        pools = [encs[k].AllocateTables(w, h, fpc) for k in range(len(ctxs))]
+        keep_tables, sats = pools, None
+        placement["chosen"] = "engine (f360_sat_tables_alloc)"
+        placement["tried"] = [p_.report for p_ in pools]
     reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
     gazes = [lissajous(g) for g in mine]
     if yuv:
@@ -387,7 +353,8 @@ def main():
     else:
         frame_ptr = [frames[k].data_ptr() for k in range(B)]
     red_ptr = [reds[k].data_ptr() for k in range(B)]
-    sat_ptr = [s.data_ptr() for s in sats]
+    sat_ptr = ([q for p_ in keep_tables for q in p_.ptrs] if sats is None
+               else [s.data_ptr() for s in sats])
     if args.print_addresses and rank == 0:
         sys.stderr.write("tables " + " ".join(hex(p) for p in sat_ptr[:6]) + " deltas " +
                          " ".join(hex(b - a) for a, b in zip(sat_ptr[:8], sat_ptr[1:9])) + "\n")
@@ -681,6 +648,9 @@ def main():
 
     for d in decs:
         d.close()
+    if sats is None:
+        for p_ in keep_tables:
+            p_.free()
     for c in ctxs:
         c.close()
     if world > 1:

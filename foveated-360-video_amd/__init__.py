@@ -90,6 +90,9 @@ _SIGNATURES = {
     "f360_sat_encode_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), c_int,
                                       c_int, c_int]),
     "f360_sat_encode_batch_max": (c_int, []),
+    "f360_sat_tables_alloc": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p)]),
+    "f360_sat_tables_free": (c_int, [c_void_p, c_void_p]),
+    "f360_sat_tables_report": (c_char_p, [c_void_p]),
     "f360_sat_encode_yuv420p_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                               POINTER(c_void_p), POINTER(c_void_p), c_int, c_int,
                                               c_int, c_int, c_int]),
@@ -392,6 +395,32 @@ def _p(x) -> c_void_p:
     return c_void_p(int(x))
 
 
+class TablePool:
+    """Tables allocated by f360_sat_tables_alloc: `.ptrs` (device pointers), `.report` (what was
+    drawn and kept), `.free()`."""
+
+    def __init__(self, ctx: "Context", width: int, height: int, count: int):
+        self._ctx = ctx
+        self._h = c_void_p()
+        out = (c_void_p * count)()
+        _check(lib().f360_sat_tables_alloc(ctx.handle, width, height, count, out, byref(self._h)))
+        self.ptrs = [int(p) for p in out]
+        self.report = lib().f360_sat_tables_report(self._h).decode()
+
+    def read_table(self, k: int, shape):
+        """Table k on the host, as uint32 of `shape` (tests)."""
+        import numpy as np
+        out = np.empty(shape, dtype=np.uint32)
+        _check(lib().f360_memcpy_d2h(self._ctx.handle, out.ctypes.data_as(c_void_p),
+                                     c_void_p(self.ptrs[k]), out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self._h:
+            _check(lib().f360_sat_tables_free(self._ctx.handle, self._h))
+            self._h = c_void_p()
+
+
 class SATEncoder:
     """sat_encoder.h:35-42.  ``SATEncoder()`` without a context is the CPU-only object of
     the reference (sat_encoder.cc:3): its GPU method reports and returns."""
@@ -423,6 +452,15 @@ class SATEncoder:
         srcs = (c_void_p * n)(*[int(p) for p in cl_source_buffers])
         _check(lib().f360_sat_encode_batch(self.cl_manager.handle, n, sats, srcs, source_width,
                                            source_height, source_linesize))
+
+    def AllocateTables(self, source_width: int, source_height: int, count: int) -> "TablePool":
+        """`count` tables for EncodeFramesGPU calls of `count` frames, placed for the read-once
+        encoder (f360_sat_tables_alloc: groups of tables are drawn, one launch is timed into each,
+        the fastest are kept).  Not in the reference."""
+        if self.cl_manager is None:
+            raise F360Error(F360_ERR_NOT_INITIALIZED,
+                            "[SATEncoder::AllocateTables] Not initialized with OpenCL")
+        return TablePool(self.cl_manager, source_width, source_height, count)
 
     def EncodeFramesYUV420PGPU(self, cl_target_buffers, planes, y_linesize: int, u_linesize: int,
                                v_linesize: int, source_width: int, source_height: int) -> None:

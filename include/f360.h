@@ -152,6 +152,24 @@ int f360_sat_encode_yuv420p(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *y_d
 int f360_sat_encode_batch(f360_ctx *ctx, int count, uint32_t *const *sat_dev,
                           const uint8_t *const *src_dev, int width, int height, int linesize);
 int f360_sat_encode_batch_max(void);
+/* Tables for f360_sat_encode_batch, placed for the read-once encoder.  A launch of that encoder
+ * writes a group of tables (32 at 8K) at the same time, and the rate at which this device takes
+ * those writes depends on what backs the tables -- 77-80 us per 8K frame or 85-94, by allocation,
+ * not by address or allocation API (profiles/round4_table_placement.txt); user space can only
+ * measure it.  This call allocates `count` tables of width x height x 12 bytes for calls of `count`
+ * frames: it draws groups (each allocated while the earlier ones are still held, alternately one
+ * allocation per table and one slab), times one encode launch of scratch frames into each, keeps the
+ * fastest and gives the rest back (transiently up to six groups more than needed; a few ms).
+ * Calls below the read-once encoder's threshold get one plain allocation per table.
+ * tables_out[k], k < count (HOST array); release with f360_sat_tables_free.  Blocks.
+ * The counterpart of the cl::Buffer allocations of src/video_server.cc:225-232 for callers
+ * that keep many frames in flight. */
+typedef struct f360_table_pool f360_table_pool;
+int f360_sat_tables_alloc(f360_ctx *ctx, int width, int height, int count, uint32_t **tables_out,
+                          f360_table_pool **pool_out);
+int f360_sat_tables_free(f360_ctx *ctx, f360_table_pool *pool);
+/* What was drawn and what was kept (a line for logs); valid until the pool is freed. */
+const char *f360_sat_tables_report(const f360_table_pool *pool);
 /* The same from planes: f360_sat_encode_yuv420p for `count` frames that share their three
  * linesizes (frames of one decoder do).  HOST arrays of device pointers. */
 int f360_sat_encode_yuv420p_batch(f360_ctx *ctx, int count, uint32_t *const *sat_dev,

@@ -54,6 +54,30 @@ class SATEncoder {
                 << f360_last_error_string() << std::endl;
   }
 
+  // Not in the reference: the tables for EncodeFramesGPU calls of `count` frames, placed for the
+  // read-once encoder (f360_sat_tables_alloc: groups of tables are drawn, one launch is timed
+  // into each, the fastest are kept).  Returns the pool to hand to FreeTablesGPU, or nullptr.
+  f360_table_pool *AllocateTablesGPU(int count, cl_mem *cl_target_buffers_out, int source_width,
+                                     int source_height) {
+    if (!use_OpenCL) {
+      std::cerr << "[SATEncoder::AllocateTablesGPU] Not initialized with OpenCL" << std::endl;
+      return nullptr;
+    }
+    f360_table_pool *pool = nullptr;
+    const int ret = f360_sat_tables_alloc(cl_manager->context.get(), source_width, source_height,
+                                          count, reinterpret_cast<uint32_t **>(cl_target_buffers_out),
+                                          &pool);
+    if (ret != F360_OK) {
+      std::cerr << "[SATEncoder::AllocateTablesGPU] failed:" << ret << " "
+                << f360_last_error_string() << std::endl;
+      return nullptr;
+    }
+    return pool;
+  }
+  void FreeTablesGPU(f360_table_pool *pool) {
+    if (use_OpenCL) (void)f360_sat_tables_free(cl_manager->context.get(), pool);
+  }
+
   // The same from a decoder's planes (frames of one decoder share their linesizes).
   void EncodeFramesYUV420PGPU(int count, cl_mem const *cl_target_buffers, cl_mem const *cl_y,
                               cl_mem const *cl_u, cl_mem const *cl_v, int y_linesize,

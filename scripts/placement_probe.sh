@@ -10,7 +10,7 @@ import json, sys
 d = json.loads(open("gpurun_out/abo.json").read().strip().splitlines()[-1])
 p = d["config"]["table_placement"]
 print(sys.argv[1], d["value"], d["path_hbm_frac"], {k: round(v.get("avg_us_per_frame", v["avg_us"]), 1) for k, v in d["kernels"].items()},
-      "tried", [(t.get("group", t.get("placement")), t["walker_us_per_frame"]) for t in p["tried"]], "chosen", p["chosen"])
+      p["chosen"], p["tried"])
 PY
 }
 for rep in 1 2 3; do

@@ -246,6 +246,32 @@ def test_a_missing_hand_off_costs_time_not_a_result(f360, oracle):
         print(f"recoveries with one-poll waits: {many}")
 
 
+def test_table_pool_allocates_usable_tables(f360, oracle):
+    """f360_sat_tables_alloc: tables for batched calls, drawn in groups and kept by measured write
+    rate.  Whatever it keeps must be `count` distinct, 16-byte aligned, non-overlapping tables
+    that the encoders fill correctly; a call below the read-once threshold gets plain
+    allocations; freeing gives everything back."""
+    with f360.Context(0) as ctx:
+        enc = f360.SATEncoder(ctx)
+        for (w, h, n, walks) in [(2304, 256, 80, True), (7680, 64, 33, True), (640, 48, 3, False)]:
+            pool = enc.AllocateTables(w, h, n)
+            assert len(pool.ptrs) == n and len(set(pool.ptrs)) == n and pool.report
+            assert ("kept" in pool.report) == walks, pool.report
+            spans = sorted(pool.ptrs)
+            assert all(p % 16 == 0 for p in spans)
+            assert all(b - a >= w * h * 12 for a, b in zip(spans, spans[1:]))
+            frames = [oracle.lcg_frame(w, h, 40 + k) for k in range(n)]
+            srcs = [ctx.upload(f) for f in frames]
+            enc.EncodeFramesGPU(pool.ptrs, [s.ptr for s in srcs], w, h, 4 * w)
+            for k in (0, n // 2, n - 1):
+                assert np.array_equal(pool.read_table(k, (h, w, 3)),
+                                      oracle.sat_encode(frames[k], w, h, 4 * w)), (w, h, n, k)
+            for s in srcs:
+                s.free()
+            pool.free()
+            pool.free()   # idempotent
+
+
 def test_walker_refuses_to_allocate_under_stream_capture(f360, oracle):
     """The first read-once call on a context allocates its hand-off buffers (and a larger call
     re-allocates them): illegal while the stream is being captured, so it is refused with a
