@@ -409,6 +409,23 @@ def test_interpolate_logpolar_and_blur(f360, gpu_ctx, oracle, w, h):
     smp.close()
 
 
+@pytest.mark.parametrize("rw,rh", [(4, 1), (8, 2), (64, 9), (70, 9), (1030, 17), (1032, 33), (4272, 2144),
+                                   (20, 64), (258, 3)])
+def test_logpolar_blur_sizes(f360, gpu_ctx, oracle, rw, rh):
+    """The blur on its own, any width and height: the left half of a row is copied (byte 3
+    zeroed), the right half filtered, edges clamped."""
+    red = oracle.lcg_frame(rw, rh, 91).reshape(rh, rw, 4)
+    want = oracle.is_logpolar_blur(red, rw, rh)
+    smp = f360.ImageSampler(gpu_ctx)
+    src, out = gpu_ctx.upload(red), gpu_ctx.malloc(rw * rh * 4)
+    out.fill(0x6B)
+    smp.ApplyLogPolarGaussianBlur(out.ptr, rw, rh, 4 * rw, src.ptr)
+    assert np.array_equal(out.copy_to_host(np.uint8, (rh, rw, 4)), want)
+    src.free()
+    out.free()
+    smp.close()
+
+
 def test_logpolar_sweep_config3(f360, gpu_ctx, oracle):
     """BASELINE config 3: 3840x1920, log-polar forward warp over the whole 17x9 gaze lattice
     (cx in {0, 1/16, .., 1}, cy in {0, 1/8, .., 1}), bilinear inverse compared at a
