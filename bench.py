@@ -341,10 +341,14 @@ def main():
         # allocated while the earlier ones are still held, times one encode launch into each
         # and keeps the fastest -- outside the timed region, once, as a caller of the
         # reference allocates its cl::Buffers once (src/video_server.cc:225-232).
-        pools = [encs[k].AllocateTables(w, h, fpc) for k in range(len(ctxs))]
-        keep_tables, sats = pools, None
-        placement["chosen"] = "engine (f360_sat_tables_alloc)"
-        placement["tried"] = [p_.report for p_ in pools]
+        try:
+            pools = [encs[k].AllocateTables(w, h, fpc) for k in range(len(ctxs))]
+            keep_tables, sats = pools, None
+            placement["chosen"] = "engine (f360_sat_tables_alloc)"
+            placement["tried"] = [p_.report for p_ in pools]
+        except f360.F360Error as e:  # (out of memory while drawing: plain allocations)
+            keep_tables, sats = alloc_tables("separate", nt_)
+            placement["chosen"] = f"separate (f360_sat_tables_alloc failed: {e})"
     reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
     gazes = [lissajous(g) for g in mine]
     if yuv:

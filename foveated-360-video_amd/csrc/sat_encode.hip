@@ -1570,7 +1570,9 @@ extern "C" int f360_sat_tables_alloc(f360_ctx *ctx, int width, int height, int c
     return st;
   };
   const int strips = (width + kStripPx - 1) / kStripPx;
-  const bool walks = walk_wanted(ctx, count, width) && width % 4 == 0;
+  // (the conditions under which f360_sat_encode_batch takes the read-once encoder)
+  const bool walks = walk_wanted(ctx, count, width) && width % 4 == 0 &&
+                     (size_t)width * height * 3 < ((size_t)1 << 31);
   char line[160];
   if (!walks) {
     for (int k = 0; k < count; ++k) {
