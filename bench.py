@@ -186,17 +186,9 @@ def main():
                          "each, keeps the fastest; read-once encoder only), separate = one torch "
                          "allocation per table, slab = one for all, separateN = one N-MiB allocation "
                          "per table")
-    ap.add_argument("--one-alloc", action="store_true",
-                    help="A/B: carve the tables of a call from one device allocation")
-    ap.add_argument("--table-pad", type=int, default=0,
-                    help="with --one-alloc: bytes between consecutive tables (multiple of 16)")
     ap.add_argument("--table-pitch-mb", type=int, default=0,
-                    help="with --one-alloc: distance between consecutive tables in MiB")
-    ap.add_argument("--table-alloc-mb", type=int, default=0,
-                    help="A/B: one allocation of this many MiB per table")
-    ap.add_argument("--table-alloc-reverse", action="store_true")
-    ap.add_argument("--print-addresses", action="store_true",
-                    help="print the device addresses of the first tables and frames on stderr")
+                    help="with --placement slab: distance between consecutive tables in MiB "
+                         "(0 = the table's size)")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (in-order streams) per GPU; frames go round-robin over them "
                          "(3 gives ~15%% more throughput; 1 keeps every kernel launch comparable with "
@@ -313,7 +305,7 @@ def main():
         allocation per table (torch.empty), "slab" = all carved from one allocation,
         "separateN" = one N-MiB allocation per table."""
         if how == "slab":
-            pitch = (args.table_pitch_mb << 20) if args.table_pitch_mb else tb + args.table_pad
+            pitch = (args.table_pitch_mb << 20) if args.table_pitch_mb else tb
             slab = torch.empty((count * pitch,), dtype=torch.uint8, device=dev)
             return slab, [slab[k * pitch:k * pitch + tb].view(torch.int32).view(h, w, 3)
                           for k in range(count)]
@@ -325,10 +317,6 @@ def main():
         return keep, keep
 
     placement = {"policy": args.placement, "tried": []}
-    if args.one_alloc:
-        args.placement = "slab"
-    if args.table_alloc_mb:
-        args.placement = f"separate{args.table_alloc_mb}"
     walks = (not args.fused and not yuv and args.placement == "auto" and
              encoder_plan(w, fpc, args.opt).startswith("read-once"))
     if not walks:
@@ -359,9 +347,6 @@ def main():
     red_ptr = [reds[k].data_ptr() for k in range(B)]
     sat_ptr = ([q for p_ in keep_tables for q in p_.ptrs] if sats is None
                else [s.data_ptr() for s in sats])
-    if args.print_addresses and rank == 0:
-        sys.stderr.write("tables " + " ".join(hex(p) for p in sat_ptr[:6]) + " deltas " +
-                         " ".join(hex(b - a) for a, b in zip(sat_ptr[:8], sat_ptr[1:9])) + "\n")
     torch.cuda.synchronize(dev)
 
     calls = [0]
