@@ -164,27 +164,20 @@ struct f360_ctx {
   // options (f360_ctx_set_option)
   int opt_band_rows = 0;       // "sat.band_rows": 0 (by frame size) | 16 | 32 | 64
   int opt_sb_bands = -1;       // "sat.sb_bands": bands per reducer wave (-1: 1 for planar sources and 64-row bands, else 2; 0: as few super-bands as 32)
-  int opt_store_mode = 1;      // "sat.store": 0 direct 48-B-stride stores, 1 LDS-staged contiguous stores
   int opt_sample_variant = 2;  // "sample.variant": 0 per-pixel, 1 column walker, 2 tile streamer (falls back to the walker where it does not apply)
   int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker
   int opt_stream_rows = 0;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64; 0 = by size (4 for a single small frame, else 8)
-  int opt_stream_depth = 2;    // "sample.depth": table rows a streamer wave keeps in flight (2 | 3 | 5)
-  int opt_stream_spread = 0;   // "sample.spread": consecutive streamer waves take tiles a quarter of the row apart instead of neighbouring ones
   int opt_sample_fpl = 16;     // "sample.fpl": frames per launch of f360_satdec_sample_rect_frames (1..64)
   int opt_batch_mb = 180;      // "sat.batch_mb": source bytes (MB) a batched encoder launch may cover
   int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows
   int opt_walk_units = 690;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder (23 frames at 8K: a launch takes at least its 480 serial batches of ~3.5 us whatever its frame count, so below ~22 frames the three kernels' 101 us per frame win; profiles/round4_few_frames.txt)
   int opt_walk_frames = 0;     // "sat.walk_frames": most frames one read-once launch takes (1..64); 0 = about 1024 strip owners, one per SIMD
-  int opt_walk_depth = 2;      // "sat.walk_depth": 8-row batches a strip owner rotates through (2 | 3), all but one in flight
-  int opt_stream_groups = 0;   // "sample.groups": the streamer stores whole 16-byte pixel groups (read-modify-write) instead of 2 + 1 bytes per pixel
-  int opt_sample_reverse = 0;  // "sample.reverse": sampler visits row runs bottom-up
   int opt_interp_staged = 1;   // "interp.staged": the un-warp computes the vertical lerps once per reduced column (wave-private LDS) instead of per output pixel
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_r2y_rows = 0;        // "yuv.r2y_rows": chroma rows a wave of the RGB0 -> yuv420p converter walks down; 0 = by frame size (16 / 8 / 4, small frames: the kernel with one chroma row per thread), -1 = always that kernel
   int opt_walk_spin = 0;       // "debug.walk_spin": polls a strip's hand-off wait may take before it finishes alone; 0 = 65536
   int opt_walk_mute = 0;       // "debug.walk_mute": test only -- unit (value - 1) of every read-once launch publishes no hand-off, so its right neighbour times out; 0 = none
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
-  int opt_reverse_tiles = 0;   // "sat.reverse": writer visits tiles in reverse of the reducer
   int opt_xcd_bands = 1;       // "is.xcd_bands": the point samplers give each XCD a band of output rows instead of every eighth workgroup: 0 never, 1 where it pays (log-rectilinear sampler, sources of 64 MB and more), 2 always
   int opt_lp_lds = 1;          // "is.lp_lds": log-polar un-warp keeps its axis tables in LDS (needs is.lp_table); 0 off, 1 on, 256 / 512 / 1024 = on with that workgroup size
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table

@@ -258,26 +258,19 @@ struct OptionSlot {
 static const OptionSlot kOptions[] = {
     {"sat.band_rows", &f360_ctx::opt_band_rows},
     {"sat.sb_bands", &f360_ctx::opt_sb_bands},
-    {"sat.store", &f360_ctx::opt_store_mode},
-    {"sat.reverse", &f360_ctx::opt_reverse_tiles},
     {"sample.variant", &f360_ctx::opt_sample_variant},
     {"sample.rows", &f360_ctx::opt_walk_rows},
     {"sample.srows", &f360_ctx::opt_stream_rows},
-    {"sample.depth", &f360_ctx::opt_stream_depth},
-    {"sample.spread", &f360_ctx::opt_stream_spread},
-    {"sample.groups", &f360_ctx::opt_stream_groups},
     {"sat.batch_mb", &f360_ctx::opt_batch_mb},
     {"sample.fpl", &f360_ctx::opt_sample_fpl},
     {"sat.walk", &f360_ctx::opt_walk},
     {"sat.walk_units", &f360_ctx::opt_walk_units},
-    {"sat.walk_depth", &f360_ctx::opt_walk_depth},
     {"sat.walk_frames", &f360_ctx::opt_walk_frames},
     {"debug.ablate", &f360_ctx::opt_ablate},
     {"debug.walk_spin", &f360_ctx::opt_walk_spin},
     {"debug.walk_mute", &f360_ctx::opt_walk_mute},
     {"interp.rows", &f360_ctx::opt_interp_rows},
     {"interp.staged", &f360_ctx::opt_interp_staged},
-    {"sample.reverse", &f360_ctx::opt_sample_reverse},
     {"yuv.model", &f360_ctx::opt_yuv_model},
     {"yuv.r2y_rows", &f360_ctx::opt_r2y_rows},
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
@@ -307,13 +300,8 @@ int f360_ctx_set_option(f360_ctx *ctx, const char *key, int value) {
         F360_REQUIRE(value >= 1 && value <= 4096, "sample.rows out of range: %d", value);
       if (s.field == &f360_ctx::opt_stream_rows)
         F360_REQUIRE(value >= 0 && value <= 64, "sample.srows out of range 0..64: %d", value);
-      if (s.field == &f360_ctx::opt_stream_depth)
-        F360_REQUIRE(value == 2 || value == 3 || value == 5, "sample.depth must be 2, 3 or 5: %d",
-                     value);
       if (s.field == &f360_ctx::opt_walk)
         F360_REQUIRE(value >= -1 && value <= 1, "sat.walk must be -1 (automatic), 0 or 1: %d", value);
-      if (s.field == &f360_ctx::opt_walk_depth)
-        F360_REQUIRE(value >= 2 && value <= 3, "sat.walk_depth must be 2 or 3: %d", value);
       if (s.field == &f360_ctx::opt_walk_frames)
         F360_REQUIRE(value >= 0 && value <= 64, "sat.walk_frames out of range 0..64: %d", value);
       if (s.field == &f360_ctx::opt_walk_units)

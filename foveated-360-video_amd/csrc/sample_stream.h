@@ -26,14 +26,10 @@
 //   * divisions use one reciprocal and, per channel, convert / add / multiply / convert:
 //     (n + 0.5) * (1/d) truncated is floor(n/d) exactly whenever the quotient is below 256 and
 //     d below 4096 (see ts_div); anything else in the wave takes the integer path.
-// Pixels are stored 2 + 1 bytes each by default: the reference writes .xyz only (byte 3 and
-// skipped pixels keep their values).  Option "sample.groups" = 1 stores whole 16-byte groups
-// instead -- a tile's main pixels are one contiguous range of reduced columns, so they are
-// packed through LDS into 4-pixel groups, merged with the destination's old groups (a third
-// LDS-direct load per row, 512 bytes) and stored with one 512-byte-contiguous instruction per
-// row; range ends that do not fill a group and the pixels of the other ranges still store
-// 2 + 1 bytes.  Measured equal within the noise (61.9 vs 62.0 us at 8K): the old groups cost
-// what the partial-sector writes cost.
+// Pixels are stored 2 + 1 bytes each: the reference writes .xyz only (byte 3 and skipped pixels
+// keep their values).  Whole 16-byte groups merged with the destination's old bytes through LDS
+// ("sample.groups", rounds 2-3) measured equal -- a 3-of-4-byte store costs a read-modify-write at
+// the DRAM whichever side does it -- and were removed in round 4 (EXPERIMENTS.md section 3).
 #pragma once
 
 #ifndef F360_TS_ST_BITS
@@ -94,10 +90,9 @@ __device__ __forceinline__ void ts_lds_wait_all(TsTexels *t) {
 constexpr int kTsTile = 128;             // texels per tile
 constexpr int kTsTileVecs = 96;          // 16-byte vectors of a full tile row segment
 constexpr int kTsMaxHaloVecs = 32;       // 512 bytes = 42 texels
-// ring slot: [0,1536) tile, [1536,2048) halo (right-aligned), with "sample.groups" also
-// [2048,2560) old pixel groups
-constexpr int ts_slot_bytes(bool groups) { return groups ? 2560 : 2048; }
-constexpr int kTsStageBytes = 128 * 4 + 64 * 4;  // packed main pixels of a row + a dummy slot per lane; before that, the schedule
+// ring slot: [0,1536) tile, [1536,2048) halo (right-aligned)
+constexpr int kTsSlotBytes = 2048;
+constexpr int kTsStageBytes = 128 * 4;  // the schedule is built here (up to 128 entries)
 constexpr int kTsPasses = 3;             // 192 candidates: 128 main + 64 others
 constexpr int kTsRanges = 5;
 constexpr int kTsMaxRows = 64;
@@ -115,36 +110,22 @@ typedef __attribute__((address_space(3))) void *ts_lptr;
 
 // The rows of one wave: NP passes of 64 lanes, NS ring slots (NS - 1 rows in flight).  The row
 // loop is not unrolled (the ring slot is a scalar), so the whole loop is a few hundred
-// instructions of straight-line code.  FAST: the main range's whole 4-pixel groups are stored
-// as 16-byte read-modify-writes (lane L owns reduced columns fg0 + 4L .. + 3, L < nfull <= 32).
-template <int NS, bool GROUPS, int NP, bool FAST>
+// instructions of straight-line code.
+template <int NS, int NP>
 __device__ __forceinline__ void tile_stream_rows(
     const SampleArgs &a, int j0, int nsched, uint32_t sched_a, uint32_t sched_b,
     const char *row0, uint32_t off_a, uint32_t off_b, uint32_t lds0, uint8_t *lds_ptr,
-    const int (&pi)[kTsPasses], const int (&ci)[kTsPasses], const bool (&is_main)[kTsPasses],
-    const uint32_t (&off_hi)[kTsPasses], const uint32_t (&off_lo)[kTsPasses],
-    const uint32_t (&dxw)[kTsPasses], int fg0, int nfull) {
-  constexpr int kTsSlotBytes = ts_slot_bytes(GROUPS);
-  constexpr int D = NS - 1;            // rows in flight
-  constexpr int LPR = FAST ? 3 : 2;    // vector-memory loads per row
-  const int lane = threadIdx.x & 63;
+    const int (&pi)[kTsPasses], const uint32_t (&off_hi)[kTsPasses],
+    const uint32_t (&off_lo)[kTsPasses], const uint32_t (&dxw)[kTsPasses]) {
+  constexpr int D = NS - 1;  // rows in flight
+  constexpr int LPR = 2;     // vector-memory loads per row
   const uint32_t row_bytes = (uint32_t)a.src_w * 12u;
   const uint32_t out_stride = (uint32_t)a.out_stride_px * 4u;
-  const uint32_t lds_stage = lds0 + NS * kTsSlotBytes;
-  const int grp = min(lane, max(nfull - 1, 0));  // lanes past the last group repeat it
-  const uint32_t grp_off = (uint32_t)(fg0 + 4 * grp) * 4u;
-  const uint32_t lds_dummy = lds_stage + 128 * 4 + (uint32_t)lane * 4u;
-  uint32_t pix_off[NP], stage_at[NP];
-  bool edge[NP], any_edge[NP], any_staged[NP], unit_p[NP];
+  uint32_t pix_off[NP];
+  bool edge[NP], any_edge[NP], unit_p[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    const int rel = ci[p] - fg0;
-    // main-range candidates inside the whole groups are staged (one that is not written stages
-    // 0, so every slot of a group is defined); written pixels outside them store 2 + 1 bytes
-    const bool staged = FAST && is_main[p] && ci[p] >= 0 && rel >= 0 && rel < 4 * nfull;
-    stage_at[p] = staged ? lds_stage + (uint32_t)rel * 4u : lds_dummy;
-    any_staged[p] = __any(staged);
-    edge[p] = pi[p] >= 0 && !staged;
+    edge[p] = pi[p] >= 0;  // this lane writes a pixel in pass p
     any_edge[p] = __any(edge[p]);
     pix_off[p] = (uint32_t)max(pi[p], 0) * 4u;
     unit_p[p] = __all(dxw[p] == 1);  // every box of the pass one texel wide: the fovea
@@ -157,19 +138,12 @@ __device__ __forceinline__ void tile_stream_rows(
     n = min(n, nsched - 1);
     return (uint32_t)__builtin_amdgcn_readlane((int)(n < 64 ? sched_a : sched_b), n & 63);
   };
-  // one row: two LDS-direct loads of 1 KiB each (+ 512 bytes of old pixel groups)
+  // one row: two LDS-direct loads of 1 KiB each
   auto issue = [&](int slot, uint32_t entry) {
     const char *row = row0 + (size_t)(entry & 0xffffu) * row_bytes;
     uint8_t *dst = lds_ptr + slot * kTsSlotBytes;
     __builtin_amdgcn_global_load_lds((ts_gptr)(row + off_a), (ts_lptr)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((ts_gptr)(row + off_b), (ts_lptr)(dst + 1024), 16, 0, 0);
-    if (FAST) {
-      const int rsel = (int)(entry >> 24);
-      const uint32_t row_off = (uint32_t)(j0 + max(rsel - 1, 0)) * out_stride;
-      if (lane < 32)
-        __builtin_amdgcn_global_load_lds((ts_gptr)(a.dst + row_off + grp_off),
-                                         (ts_lptr)(dst + 2048), 16, 0, 0);
-    }
   };
 #pragma unroll
   for (int k = 0; k < D; ++k) issue(k, entry_at(k));
@@ -230,27 +204,9 @@ __device__ __forceinline__ void tile_stream_rows(
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const uint32_t rg = (q[p].x & 0xffu) | ((q[p].y & 0xffu) << 8);
-        if (FAST && any_staged[p])  // 0xff in byte 3 marks a pixel that is written
-          lds_store4(stage_at[p], pi[p] >= 0 ? (rg | ((q[p].z & 0xffu) << 16) | 0xff000000u) : 0u);
         if (any_edge[p] && !(a.ablate & 16)) {
           if (edge[p]) store_rgb_uncounted(a.dst, row_off + pix_off[p], rg, q[p].z);
         }
-      }
-      if (FAST) {
-        u32x4_t px, old;
-        asm volatile(
-            "ds_read_b128 %0, %2\n\t"
-            "ds_read_b128 %1, %3\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(px), "=&v"(old)
-            : "v"(lds_stage + (uint32_t)grp * 16u), "v"(slot_base + 2048u + (uint32_t)grp * 16u)
-            : "memory");
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint32_t m = (uint32_t)((int32_t)px[c] >> 31) & 0x00ffffffu;
-          old[c] = (px[c] & m) | (old[c] & ~m);
-        }
-        if (!(a.ablate & 16)) store_b128_uncounted(a.dst, row_off + grp_off, old);
       }
     }
 #pragma unroll
@@ -263,13 +219,12 @@ __device__ __forceinline__ void tile_stream_rows(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NS, bool GROUPS>
+template <int NS>
 __device__ __forceinline__ void tile_stream_body(const SampleArgs &a, int tile, int j0, int rows,
                                              uint32_t lds0, uint8_t *lds_ptr) {
   const int lane = threadIdx.x & 63;
   const int src_w = a.src_w;
   const int ntiles = (src_w + kTsTile - 1) / kTsTile;
-  constexpr int kTsSlotBytes = ts_slot_bytes(GROUPS);
   const uint32_t lds_stage = lds0 + NS * kTsSlotBytes;  // the schedule is built here
   const int x_tile = tile * kTsTile;
 
@@ -341,7 +296,7 @@ __device__ __forceinline__ void tile_stream_body(const SampleArgs &a, int tile, 
   }
   AxisBox bx[kTsPasses];
   int need_halo = 0;
-  bool any_mine = false, foreign = false;
+  bool any_mine = false;
 #pragma unroll
   for (int p = 0; p < kTsPasses; ++p) {
     pi[p] = -1;
@@ -351,8 +306,6 @@ __device__ __forceinline__ void tile_stream_body(const SampleArgs &a, int tile, 
         pi[p] = ci[p];
         need_halo = max(need_halo, x_tile - bx[p].lo);
         any_mine = true;
-      } else if (bx[p].ok && is_main[p]) {
-        foreign = true;  // another tile's pixel inside this tile's main range
       }
     }
   }
@@ -411,41 +364,25 @@ __device__ __forceinline__ void tile_stream_body(const SampleArgs &a, int tile, 
   else
     off_b = halo_vecs > 0 ? (uint32_t)(512 - hb + min(lane - 32, halo_vecs - 1) * 16) : 512u;
 
-  // whole-group stores need a main range without foreign pixels and at least one whole group
-  const int fg0 = (first_main + 3) & ~3;
-  const int nfull = min((first_main + cnt_main - fg0) >> 2, 32);
-  const bool fast = GROUPS && !__any(foreign) && nfull >= 1;
-#define TS_ROWS(N, F)                                                                        \
-  tile_stream_rows<NS, GROUPS, N, F>(a, j0, nsched, sched_a, sched_b, row0, off_a, off_b, lds0, lds_ptr, \
-                         pi, ci, is_main, off_hi, off_lo, dxw, F ? fg0 : 0, F ? nfull : 0)
-  if (GROUPS && fast) {
-    if (np <= 1) TS_ROWS(1, GROUPS);
-    else if (np == 2) TS_ROWS(2, GROUPS);
-    else TS_ROWS(3, GROUPS);
-  } else {
-    if (np <= 1) TS_ROWS(1, false);
-    else if (np == 2) TS_ROWS(2, false);
-    else TS_ROWS(3, false);
-  }
+#define TS_ROWS(N) \
+  tile_stream_rows<NS, N>(a, j0, nsched, sched_a, sched_b, row0, off_a, off_b, lds0, lds_ptr, pi, off_hi, off_lo, dxw)
+  if (np <= 1) TS_ROWS(1);
+  else if (np == 2) TS_ROWS(2);
+  else TS_ROWS(3);
 #undef TS_ROWS
 }
 
-// Work items = (row block, tile); consecutive waves take tiles `istride` apart (coprime to the
-// tile count, about a quarter of it), so the four waves of a workgroup -- and with them every
-// CU -- get the same mix of fovea and periphery tiles.
-template <int NS, bool GROUPS>
+// Work items = (row block, tile), four consecutive tiles per workgroup.
+template <int NS>
 __global__ __launch_bounds__(256) void sample_rect_stream_kernel(const SampleArgs a, int rows,
-                                                                  int nblocks, int rot,
-                                                                  int istride) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[4][NS * ts_slot_bytes(GROUPS) + kTsStageBytes];
+                                                                  int nblocks) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[4][NS * kTsSlotBytes + kTsStageBytes];
   const int wave = threadIdx.x >> 6;
   const int ntiles = (a.src_w + kTsTile - 1) / kTsTile;
   const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
   if (g >= ntiles * nblocks) return;
   const int blk = g / ntiles;
-  int t = (int)(((unsigned)(g - blk * ntiles) * (unsigned)istride) % (unsigned)ntiles) + rot;
-  if (t >= ntiles) t -= ntiles;
-  tile_stream_body<NS, GROUPS>(a, t, blk * rows, rows,
-                   (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]), &stage[wave][0]);
+  tile_stream_body<NS>(a, g - blk * ntiles, blk * rows, rows,
+                       (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]), &stage[wave][0]);
 }
 

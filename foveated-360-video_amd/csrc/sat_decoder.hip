@@ -134,8 +134,6 @@ struct SampleArgs {
   const int *lbx;
   int lb_dmin, lb_n, halo;
   int ablate;                  // timing experiments only
-  int reverse;                 // visit the row runs bottom-up (the table's last rows are the
-                               // most recently written, hence the likeliest to be cached)
 };
 
 // Non-temporal: the reduced frame is read next by a copy engine or another kernel, and dirty lines
@@ -233,7 +231,7 @@ __global__ __launch_bounds__(256) void sample_rect_walk_kernel(const SampleArgs 
   const int c0 = __builtin_amdgcn_readfirstlane(
       ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * kWalkCols);
   if (c0 >= a.out_w) return;  // whole wave
-  const int by = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int by = (int)blockIdx.y;
   const int j0 = by * rows;
   walk_body(a, c0, 0, a.out_w, j0, min(j0 + rows, a.out_h));
 }
@@ -285,7 +283,7 @@ template <int NS>
 __global__ __launch_bounds__(256) void sample_rect_stream_batch_kernel(SampleArgs a,
                                                                         const SampleBatch b,
                                                                         int rows, int nblocks) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[4][NS * ts_slot_bytes(false) + kTsStageBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[4][NS * kTsSlotBytes + kTsStageBytes];
   const int wave = threadIdx.x >> 6;
   const int z = blockIdx.y;
   a.dst = b.dst[z];
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(256) void sample_rect_stream_batch_kernel(SampleArg
   const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
   if (g >= ntiles * nblocks) return;
   const int blk = g / ntiles;
-  tile_stream_body<NS, false>(a, g - blk * ntiles, blk * rows, rows,
+  tile_stream_body<NS>(a, g - blk * ntiles, blk * rows, rows,
                               (uint32_t)reinterpret_cast<uintptr_t>(&stage[wave][0]),
                               &stage[wave][0]);
 }
@@ -1140,7 +1138,6 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   sa.lb_n = dec->lb_n;
   sa.halo = dec->halo;
   sa.ablate = ctx->opt_ablate;
-  sa.reverse = ctx->opt_sample_reverse;
   const int variant = ctx->opt_sample_variant;
   const bool can_stream = tile_stream_applies(dec, sat_dev, source_width, source_height,
                                               target_linesize, target_height);
@@ -1159,23 +1156,11 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
                                 : (long)target_height * ((source_width + kTsTile - 1) / kTsTile) < 20000 ? 4 : 8,
                                 kTsMaxRows);
       const int nblocks = (target_height + rows - 1) / rows;
-      int istride = ctx->opt_stream_spread ? std::max(ntiles / 4, 1) : 1;
-      while (std::gcd(istride, ntiles) != 1) ++istride;
+      // (a ring of 3 slots: two table rows in flight; rings of 4 and 6, a tile order spread over
+      // the XCDs and 16-byte group stores were A/B switches until round 4: EXPERIMENTS.md 3)
       const dim3 sgrid((unsigned)((ntiles * nblocks + 3) / 4));
-#define F360_TS_LAUNCH(NS, G)                                                                  \
-  hipLaunchKernelGGL((sample_rect_stream_kernel<NS, G>), sgrid, dim3(256), 0, ctx->stream, sa, \
-                     rows, nblocks, 0, istride)
-      const int depth = ctx->opt_stream_depth;
-      if (ctx->opt_stream_groups) {
-        if (depth <= 2) F360_TS_LAUNCH(3, true);
-        else if (depth <= 3) F360_TS_LAUNCH(4, true);
-        else F360_TS_LAUNCH(6, true);
-      } else {
-        if (depth <= 2) F360_TS_LAUNCH(3, false);
-        else if (depth <= 3) F360_TS_LAUNCH(4, false);
-        else F360_TS_LAUNCH(6, false);
-      }
-#undef F360_TS_LAUNCH
+      hipLaunchKernelGGL(sample_rect_stream_kernel<3>, sgrid, dim3(256), 0, ctx->stream, sa, rows,
+                         nblocks);
       streamed = true;
     }
   }
@@ -1263,15 +1248,8 @@ static int sample_rect_batch_impl(f360_sat_decoder *dec, uint8_t *const *targets
     const int rows = std::min(ctx->opt_stream_rows > 0 ? ctx->opt_stream_rows : 8, kTsMaxRows);
     const int nblocks = (target_height + rows - 1) / rows;
     const dim3 sgrid((unsigned)((ntiles * nblocks + 3) / 4), (unsigned)count);
-    if (ctx->opt_stream_depth <= 2)
-      hipLaunchKernelGGL(sample_rect_stream_batch_kernel<3>, sgrid, dim3(256), 0, ctx->stream, sa,
-                         b, rows, nblocks);
-    else if (ctx->opt_stream_depth <= 3)
-      hipLaunchKernelGGL(sample_rect_stream_batch_kernel<4>, sgrid, dim3(256), 0, ctx->stream, sa,
-                         b, rows, nblocks);
-    else
-      hipLaunchKernelGGL(sample_rect_stream_batch_kernel<6>, sgrid, dim3(256), 0, ctx->stream, sa,
-                         b, rows, nblocks);
+    hipLaunchKernelGGL(sample_rect_stream_batch_kernel<3>, sgrid, dim3(256), 0, ctx->stream, sa, b,
+                       rows, nblocks);
   } else {
     const int rows = ctx->opt_walk_rows;
     const dim3 grid((target_width + 4 * kWalkCols - 1) / (4 * kWalkCols),

@@ -142,7 +142,6 @@ struct EncodeArgs {
   int width, height, linesize, bpp;
   int band_rows, sb_bands, nstrips, nbands, nsb, wp3;
   uint32_t *lp, *sbtotal, *sbprefix, *rowsum, *rowcarry, *tiletotal, *tprefix;
-  int reverse;
   int ablate;  // timing experiments only (results are wrong when non-zero)
   // STORE == 2 (fused foveation): instead of the table, emit only the entries at the
   // lattice rows / columns a given gaze will sample
@@ -590,7 +589,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_kernel(
   const int wave = threadIdx.x >> 6;
   int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kWavesPerBlock + wave);
   if (tile >= a.nstrips * a.nbands) return;  // 1-D grid over the tiles, see sat_reduce_kernel
-  if (a.reverse) tile = a.nstrips * a.nbands - 1 - tile;
   F360_ENCODE_FRAME(fr, a, eb)
   const int band = tile / a.nstrips;
   const int strip = tile - band * a.nstrips;
@@ -1297,7 +1295,6 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   a.rowcarry = p.rowcarry;
   a.tiletotal = p.tiletotal;
   a.tprefix = p.tprefix;
-  a.reverse = ctx->opt_reverse_tiles;
   a.ablate = ctx->opt_ablate;
   a.xmap = emit ? emit->xmap : nullptr;
   a.ymap = emit ? emit->ymap : nullptr;
@@ -1381,10 +1378,9 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
       hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 2>), grid3, block, 0, ctx->stream, a, eb);
     else if (!vec)
       hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 0>), grid3, block, 0, ctx->stream, a, eb);
-    else if (ctx->opt_store_mode == 1)
+    else  // (direct 48-byte-stride stores for RGB0 frames, "sat.store" = 0, were an A/B switch
+          // until round 4: 136 against 88 us at 8K)
       hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 1>), grid3, block, 0, ctx->stream, a, eb);
-    else
-      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 0>), grid3, block, 0, ctx->stream, a, eb);
   }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;
@@ -1488,7 +1484,6 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   p.walk_stats_units = per_launch * nstrips;
   p.walk_stats_offset = gran_bytes;
   const int yuv_src = !yuvs ? 0 : ctx->opt_yuv_model == 1 ? kSrcYuvSwsX86 : kSrcYuvSwsC;
-  const int depth = ctx->opt_walk_depth;
 
   for (int k0 = 0; k0 < count; k0 += per_launch) {
     const int n = std::min(count - k0, per_launch);
@@ -1505,12 +1500,7 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
     const dim3 block(64 * kWalkWaves);
     f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
 #define F360_WALK_LAUNCH(SRC)                                                                   \
-  do {                                                                                          \
-    if (depth <= 2)                                                                             \
-      hipLaunchKernelGGL((sat_walk_kernel<SRC, 2>), grid, block, 0, ctx->stream, a, wb);        \
-    else                                                                                        \
-      hipLaunchKernelGGL((sat_walk_kernel<SRC, 3>), grid, block, 0, ctx->stream, a, wb);        \
-  } while (0)
+  hipLaunchKernelGGL((sat_walk_kernel<SRC, 2>), grid, block, 0, ctx->stream, a, wb)
     if (yuv_src == kSrcYuvSwsX86)
       F360_WALK_LAUNCH(kSrcYuvSwsX86);
     else if (yuv_src == kSrcYuvSwsC)

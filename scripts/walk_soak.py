@@ -41,8 +41,7 @@ while time.time() - t0 < budget:
     tabs = [torch.zeros((count, h, w, 3), dtype=torch.int32, device=dev) for _ in range(2)]
     # (now and then with hand-off waits one to a few polls long: strips drop off the chain and
     # finish alone -- the recovery path must give the same tables)
-    opts = {"sat.walk_depth": int(rng.choice([2, 3])),
-            "sat.walk_frames": int(rng.choice([0, 0, 1, 3, 8, 64])),
+    opts = {"sat.walk_frames": int(rng.choice([0, 0, 1, 3, 8, 64])),
             "debug.walk_spin": int(rng.choice([0, 0, 0, 1, 7, 40]))}
     for k, v in opts.items():
         ctx.set_option(k, v)
@@ -87,7 +86,7 @@ while time.time() - t0 < budget:
         if len(worst) < 12:
             worst.append((w, h, count, linesize, opts, ok_walk, ok_three))
     del src, tabs, px, want
-for k, v in (("sat.walk", -1), ("sat.walk_depth", 2), ("sat.walk_frames", 0), ("debug.walk_spin", 0)):
+for k, v in (("sat.walk", -1), ("sat.walk_frames", 0), ("debug.walk_spin", 0)):
     ctx.set_option(k, v)
 print({"cases": cases, "planar_cases": planar_cases, "frames": frames_done, "bad_cases": bad, "first_failures": worst,
        "seconds": round(time.time() - t0, 1)})

@@ -87,18 +87,16 @@ def test_sat_encode_matches_oracle(f360, gpu_ctx, oracle, w, h, bpp, pad, off):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("band_rows,sb_bands,store", [(16, 8, 0), (32, 8, 1), (64, 4, 0),
-                                                      (32, 1, 0), (16, 64, 1), (32, 3, 1),
-                                                      (8, 1, 1), (8, 2, 0), (8, 5, 1)])
-def test_sat_encode_tiling_options(f360, gpu_ctx, oracle, band_rows, sb_bands, store):
+@pytest.mark.parametrize("band_rows,sb_bands", [(16, 8), (32, 8), (64, 4), (32, 1), (16, 64), (32, 3),
+                                                (8, 1), (8, 2), (8, 5)])
+def test_sat_encode_tiling_options(f360, gpu_ctx, oracle, band_rows, sb_bands):
     w, h = 1336, 203  # neither a multiple of the strip nor of any band height
     frame = oracle.lcg_frame(w, h, 77)
     want = oracle.sat_encode(frame, w, h, 4 * w)
-    old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands", "sat.store")}
+    old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands")}
     try:
         gpu_ctx.set_option("sat.band_rows", band_rows)
         gpu_ctx.set_option("sat.sb_bands", sb_bands)
-        gpu_ctx.set_option("sat.store", store)
         got = gpu_sat(f360, gpu_ctx, frame, w, h, 4 * w)
     finally:
         for k, v in old.items():
@@ -680,16 +678,15 @@ def test_send_frame_loop_config5_8k(f360, gpu_ctx, oracle, tmp_path):
 @pytest.mark.parametrize("w,h", [(1920, 1080), (1028, 300)])
 def test_tile_streamer_options(f360, gpu_ctx, oracle, w, h):
     """The tile streamer across its launch shapes: rows per wave (1 .. 64, incl. runs that do not
-    divide the height), table rows in flight, tile order, 16-byte group stores; gazes on the
-    seam, outside the frame and in the corners exercise the wrap states, the halo and the
-    schedule's extra top rows."""
+    divide the height); gazes on the seam, outside the frame and in the corners exercise the
+    wrap states, the halo and the schedule's extra top rows."""
     rw, rh = reduced(w), reduced(h)
     frame = oracle.lcg_frame(w, h, 77)
     sat_h = oracle.sat_encode(frame, w, h, 4 * w)
     grid = oracle.satdec_grid(rw, rh, w, h)
     dec = f360.SATDecoder(gpu_ctx)
     dec.InitializeGrid(rw, rh, w, h)
-    keys = ("sample.variant", "sample.srows", "sample.depth", "sample.spread", "sample.groups")
+    keys = ("sample.variant", "sample.srows")
     old = {k: gpu_ctx.get_option(k) for k in keys}
     gpu_ctx.set_option("sample.variant", 2)
     gazes = [(0.5, 0.5), (0.0, 0.0), (0.999, 0.5), (1.0, 1.0), (-0.2, 1.3), (0.031, 0.77), (1.4, -0.3)]
@@ -698,13 +695,11 @@ def test_tile_streamer_options(f360, gpu_ctx, oracle, w, h):
         want = np.full((rh, 4 * rw + 8), 0xA5, dtype=np.uint8)
         oracle.satdec_sample_rect(want, rw, rh, 4 * rw + 8, sat_h, w, h, grid, cx, cy)
         wants.append(want)
-    for srows, depth, spread, groups in [(1, 2, 0, 0), (7, 3, 1, 1), (16, 5, 0, 1), (32, 3, 1, 0),
-                                         (64, 2, 0, 1), (64, 5, 1, 0), (8, 2, 0, 1), (8, 2, 1, 0)]:
-        for k, v in zip(keys[1:], (srows, depth, spread, groups)):
-            gpu_ctx.set_option(k, v)
+    for srows in (1, 7, 16, 32, 64, 8, 0):
+        gpu_ctx.set_option("sample.srows", srows)
         for (cx, cy), want in zip(gazes, wants):
             got = run_sample_rect(f360, gpu_ctx, dec, sat_h, w, h, rw, rh, cx, cy, pad=8)
-            assert np.array_equal(got, want), (srows, depth, spread, groups, cx, cy)
+            assert np.array_equal(got, want), (srows, cx, cy)
     for k, v in old.items():
         gpu_ctx.set_option(k, v)
     dec.close()

@@ -42,7 +42,7 @@ def random_gaze(rng):
 def test_random_sat_encode(f360, gpu_ctx, oracle):
     rng = np.random.default_rng(20240601)
     enc = f360.SATEncoder(gpu_ctx)
-    old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands", "sat.store")}
+    old = {k: gpu_ctx.get_option(k) for k in ("sat.band_rows", "sat.sb_bands")}
     try:
         for case in range(60 * SCALE):
             w, h = random_geometry(rng)
@@ -53,7 +53,6 @@ def test_random_sat_encode(f360, gpu_ctx, oracle):
                 ls = w * bpp
             gpu_ctx.set_option("sat.band_rows", int(rng.choice([0, 8, 16, 32, 64])))
             gpu_ctx.set_option("sat.sb_bands", int(rng.choice([0, 1, 2, 3, 8])))
-            gpu_ctx.set_option("sat.store", int(rng.integers(0, 2)))
             frame = rng.integers(0, 256, (h, ls), dtype=np.uint8)
             if case % 7 == 0:
                 frame[:] = 255
@@ -238,7 +237,6 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
         # the read-once strip walker whenever the layout allows it (every other case), with
         # random depth and frames per launch; else the automatic choice (three kernels here)
         gpu_ctx.set_option("sat.walk", 1 if case % 2 else -1)
-        gpu_ctx.set_option("sat.walk_depth", int(rng.choice([2, 3])))
         gpu_ctx.set_option("sat.walk_frames", int(rng.choice([0, 1, 3, 7, 64])))
         frames = [rng.integers(0, 256, (h, ls), dtype=np.uint8) for _ in range(n)]
         gazes = [random_gaze(rng) for _ in range(n)]
@@ -264,7 +262,6 @@ def test_random_frames_in_shared_launches(f360, gpu_ctx, oracle):
         dec.close()
     gpu_ctx.set_option("sample.variant", DEFAULT_SAMPLER)
     gpu_ctx.set_option("sat.walk", -1)
-    gpu_ctx.set_option("sat.walk_depth", 2)
     gpu_ctx.set_option("sat.walk_frames", 0)
 
 

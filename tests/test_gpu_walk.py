@@ -37,7 +37,6 @@ def walk_ctx(gpu_ctx):
     gpu_ctx.set_option("sat.walk", 1)
     yield gpu_ctx
     gpu_ctx.set_option("sat.walk", -1)
-    gpu_ctx.set_option("sat.walk_depth", 2)
 
 
 @pytest.mark.parametrize("w,h,n,pad", [
@@ -51,13 +50,6 @@ def walk_ctx(gpu_ctx):
 ])
 def test_walk_encode_matches_oracle(f360, walk_ctx, oracle, w, h, n, pad):
     assert _encode_batch_and_check(f360, walk_ctx, oracle, w, h, n, pad) == []
-
-
-@pytest.mark.parametrize("depth", [2, 3])
-def test_walk_depths(f360, walk_ctx, oracle, depth):
-    walk_ctx.set_option("sat.walk_depth", depth)
-    for w, h, n in [(1336, 203, 3), (2048, 50, 4), (772, 23, 2)]:
-        assert _encode_batch_and_check(f360, walk_ctx, oracle, w, h, n) == [], (w, h, n)
 
 
 def test_walk_repeated_and_recarved(f360, walk_ctx, oracle):
