@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="FoveateFrameRectGPU (encode + sample without writing the table) instead "
                          "of the two reference calls")
+    ap.add_argument("--one-pass", choices=["on", "off"], default="off",
+                    help="on: EncodeSampleFramesGPU (tables AND reduced frames from one pass of the "
+                         "read-once encoder; RGB0 sources) instead of EncodeFramesGPU + SampleFramesRectGPU")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the short untimed-region measurements of the fused / planar variants")
     ap.add_argument("--share-device", action="store_true",
@@ -350,6 +353,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     calls = [0]
+    one_pass = args.one_pass == "on" and not yuv and not args.fused and fpc > 1
 
     def step_batched(profile):
         # frames [g, g + n) in one encode call and one sample call; --profile-every counts
@@ -365,14 +369,18 @@ def main():
                 for o in range(nstreams):
                     if o != s:
                         streams[s].wait_stream(streams[o])
-                ctxs[s].profile_arm(2)
+                ctxs[s].profile_arm(1 if one_pass else 2)
             mine_sats = sat_ptr[s * fpc:s * fpc + n]
-            if yuv:
+            if one_pass:
+                decs[s].EncodeSampleFramesGPU(red_ptr[g:g + n], rw, rh, 4 * rw, mine_sats,
+                                              frame_ptr[g:g + n], w, h, 4 * w, gazes[g:g + n])
+            elif yuv:
                 encs[s].EncodeFramesYUV420PGPU(mine_sats, yuv_ptr[g:g + n], w, w // 2, w // 2, w, h)
             else:
                 encs[s].EncodeFramesGPU(mine_sats, frame_ptr[g:g + n], w, h, 4 * w)
-            decs[s].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, mine_sats, (w, h),
-                                        gazes[g:g + n])
+            if not one_pass:
+                decs[s].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, mine_sats, (w, h),
+                                            gazes[g:g + n])
             if sampled:
                 for o in range(nstreams):
                     if o != s:

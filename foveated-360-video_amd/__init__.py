@@ -113,6 +113,9 @@ _SIGNATURES = {
     "f360_satdec_sample_rect_frames": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                                c_int, POINTER(c_void_p), c_int, c_int,
                                                POINTER(c_float)]),
+    "f360_satdec_encode_sample_frames": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
+                                                 POINTER(c_void_p), c_int, c_int, c_int, c_int,
+                                                 c_int, c_int, c_int, POINTER(c_float)]),
     "f360_satdec_foveate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                          c_int, c_int, c_float, c_float]),
     "f360_satdec_foveate_rect_yuv420p": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
@@ -561,6 +564,26 @@ class SATDecoder:
         _check(lib().f360_satdec_sample_rect_frames(self._h, ptrs, n, target_width,
                                                     target_height, target_linesize, sats, w, h,
                                                     xy))
+
+    def EncodeSampleFramesGPU(self, cl_target_buffers, target_width, target_height,
+                              target_linesize, cl_tables, cl_source_frames, source_width,
+                              source_height, source_linesize, centers) -> None:
+        """SATEncoder.EncodeFramesGPU + SampleFramesRectGPU for frames whose gaze is known before
+        the encode (f360_satdec_encode_sample_frames): the same tables and reduced frames; with
+        enough frames for the read-once encoder the reduced pixels come out of its pass and the
+        tables are not read back."""
+        self._need("EncodeSampleFramesGPU")
+        n = len(cl_target_buffers)
+        if n != len(cl_tables) or n != len(cl_source_frames) or n != len(centers):
+            raise ValueError("EncodeSampleFramesGPU: as many targets as tables, frames and gaze points")
+        dsts = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        sats = (c_void_p * n)(*[int(p) for p in cl_tables])
+        srcs = (c_void_p * n)(*[int(p) for p in cl_source_frames])
+        xy = (c_float * (2 * n))(*[float(v) for c in centers for v in c])
+        _check(lib().f360_satdec_encode_sample_frames(self._h, dsts, sats, srcs, n, target_width,
+                                                      target_height, target_linesize,
+                                                      source_width, source_height,
+                                                      source_linesize, xy))
 
     def FoveateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
                             target_linesize, cl_source_frame, source_width, source_height,

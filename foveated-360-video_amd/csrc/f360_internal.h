@@ -101,6 +101,7 @@ struct SatEncodePlan {
   // read-once batched encoder (sat_walk_kernel): hand-off granules, the launch state words
   // (device memory, advanced by the launches themselves) and the host-mapped error word
   DevBuf walk_chain, walk_state;
+  DevBuf walk_plan;  // encode + sample: per frame of a launch, one plan word per table row
   uint32_t *walk_err_host = nullptr, *walk_err_dev = nullptr;
   int walk_stats_units = 0;       // debug statistics behind the granules (debug.ablate bit 8)
   size_t walk_stats_offset = 0;
@@ -147,6 +148,8 @@ enum KernelId {
   kYuvToRgb,
   kRgbToYuv,
   kExpand,
+  kWalkFusePlan,
+  kWalkFuseFix,
   kKernelCount
 };
 struct ProfSpan {
@@ -183,6 +186,7 @@ struct f360_ctx {
   int opt_lp_table = 1;        // "is.lp_table": log-polar un-warp reads its inverse map from a per-geometry table
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos)
   int opt_gnomonic_guard = 1;  // "gnomonic.guard": texel indices from a cheap float evaluation wherever its error bound decides them, the exact chain for the others (64 at a time)
+  int opt_fuse_walk = 1;       // "fuse.walk": f360_satdec_encode_sample_frames samples inside the read-once encoder's pass wherever it applies; 0 = always the two calls
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
@@ -266,6 +270,22 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                     int count = 0, uint32_t *const *sats = nullptr,
                     const uint8_t *const *srcs = nullptr, int profile = -1,
                     const YuvPlanes *yuvs = nullptr);
+}  // namespace f360
+
+namespace f360 {
+// Encode + sample in one pass over the frames (sat_encode.hip: sat_walk_kernel<.., true>): where
+// the reduced frames go, the gaze of every frame, the decoder's 1-D grid factors (device).
+struct SatFuse {
+  uint8_t *const *dsts;
+  const float *centers_xy;
+  const int16_t *gx, *gy;
+  int out_w, out_h, dst_linesize;
+};
+bool sat_encode_sample_applies(const f360_ctx *ctx, int count, int width, int height,
+                               int linesize, int out_w, int out_h, int dst_linesize);
+int sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats,
+                           const uint8_t *const *srcs, int width, int height, int linesize,
+                           const SatFuse &fuse, bool prof);
 }  // namespace f360
 
 struct f360_event {

@@ -111,6 +111,7 @@ int f360_ctx_destroy(f360_ctx *ctx) {
   ctx->enc.ws.release();
   ctx->enc.walk_chain.release();
   ctx->enc.walk_state.release();
+  ctx->enc.walk_plan.release();
   if (ctx->enc.walk_err_host) (void)hipHostFree(ctx->enc.walk_err_host);
   ctx->ex_tables.release();
   ctx->gn_table.release();
@@ -274,6 +275,7 @@ static const OptionSlot kOptions[] = {
     {"yuv.model", &f360_ctx::opt_yuv_model},
     {"yuv.r2y_rows", &f360_ctx::opt_r2y_rows},
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
+    {"fuse.walk", &f360_ctx::opt_fuse_walk},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},
     {"is.lp_table", &f360_ctx::opt_lp_table},
@@ -341,7 +343,8 @@ static const char *const kKernelNames[f360::kKernelCount] = {
     "is_sample_rect_kernel",    "is_sample_logpolar_kernel",
     "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel",
     "foveate_maps_kernel",      "sample_compact_kernel",  "yuv420p_to_rgb0_kernel",
-    "rgb0_to_yuv420p_kernel",   "expand_kernel"};
+    "rgb0_to_yuv420p_kernel",   "expand_kernel",          "walk_fuse_plan_kernel",
+    "walk_fuse_fix_kernel"};
 
 int f360_kernel_count(void) { return f360::kKernelCount; }
 

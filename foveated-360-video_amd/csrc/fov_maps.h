@@ -35,6 +35,27 @@ __device__ __forceinline__ AxisBox sample_axis(int centre, int d_hi, int d_lo, i
   return b;
 }
 
+// The three channel quotients of one box, exact.  Common case (all operands
+// < 2^22): ONE hardware reciprocal (1 ulp) shared by the channels, a float
+// multiply per channel -- off by at most one, since n/d < 2^22 and the relative
+// error is < 2^-22 -- then the exact remainder decides the +-1 correction.
+static __device__ __noinline__ uint3 udiv3_slow(uint3 n, uint32_t d) {
+  return make_uint3(n.x / d, n.y / d, n.z / d);
+}
+__device__ __forceinline__ uint32_t udiv_by_rcp(uint32_t n, float inv, uint32_t d) {
+  uint32_t q = (uint32_t)((float)n * inv);
+  const uint32_t r = n - __umul24(q, d);
+  if ((int32_t)r < 0) q -= 1;
+  else if (r >= d) q += 1;
+  return q;
+}
+__device__ __forceinline__ uint3 udiv3_exact(uint3 n, uint32_t d) {
+  if (((n.x | n.y | n.z | d) >> 22) != 0) return udiv3_slow(n, d);
+  const float inv = __builtin_amdgcn_rcpf((float)d);
+  return make_uint3(udiv_by_rcp(n.x, inv, d), udiv_by_rcp(n.y, inv, d),
+                    udiv_by_rcp(n.z, inv, d));
+}
+
 // Fused foveation (SURVEY.md 8f-1 i): which table rows / columns a gaze samples, numbered.
 struct FovMaps {
   const int16_t *gx, *gy;

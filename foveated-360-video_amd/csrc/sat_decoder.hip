@@ -32,6 +32,7 @@ namespace {
 using f360::AxisBox;
 using f360::FovMaps;
 using f360::sample_axis;  // one axis of sample_rect_kernel's box rule (fov_maps.h)
+using f360::udiv3_exact;  // the three channel quotients of one box (fov_maps.h)
 
 __device__ __forceinline__ uint3 load_sat3(const uint32_t *sat, size_t texel) {
   const uint32_t *p = sat + texel * 3;
@@ -47,27 +48,6 @@ __device__ __forceinline__ uint32_t udiv_exact(uint32_t n, uint32_t d) {
     return (uint32_t)((float)n / (float)d);
   }
   return n / d;
-}
-
-// The three channel quotients of one box, exact.  Common case (all operands
-// < 2^22): ONE hardware reciprocal (1 ulp) shared by the channels, a float
-// multiply per channel -- off by at most one, since n/d < 2^22 and the relative
-// error is < 2^-22 -- then the exact remainder decides the +-1 correction.
-__device__ __noinline__ uint3 udiv3_slow(uint3 n, uint32_t d) {
-  return make_uint3(n.x / d, n.y / d, n.z / d);
-}
-__device__ __forceinline__ uint32_t udiv_by_rcp(uint32_t n, float inv, uint32_t d) {
-  uint32_t q = (uint32_t)((float)n * inv);
-  const uint32_t r = n - __umul24(q, d);
-  if ((int32_t)r < 0) q -= 1;
-  else if (r >= d) q += 1;
-  return q;
-}
-__device__ __forceinline__ uint3 udiv3_exact(uint3 n, uint32_t d) {
-  if (((n.x | n.y | n.z | d) >> 22) != 0) return udiv3_slow(n, d);
-  const float inv = __builtin_amdgcn_rcpf((float)d);
-  return make_uint3(udiv_by_rcp(n.x, inv, d), udiv_by_rcp(n.y, inv, d),
-                    udiv_by_rcp(n.z, inv, d));
 }
 
 // 12-byte texel at a 32-bit BYTE offset from the table base (the table is < 4 GiB on
@@ -1292,6 +1272,68 @@ int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *target
     if (st != F360_OK) return st;
   }
   return F360_OK;
+}
+
+// Encode + sample in one pass over the frames: tables AND reduced frames, byte for byte what
+// f360_sat_encode_batch followed by f360_satdec_sample_rect_frames leave (which is what this
+// call does whenever the one-pass form does not apply: too few frames for the read-once encoder,
+// a source that is not 16-byte aligned RGB0, a grid whose offsets do not increase strictly).
+int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                     uint32_t *const *sats_dev, const uint8_t *const *sources_dev,
+                                     int count, int target_width, int target_height,
+                                     int target_linesize, int source_width, int source_height,
+                                     int source_linesize, const float *centers_xy) {
+  F360_REQUIRE(dec && targets_dev && sats_dev && sources_dev && centers_xy && count >= 1,
+               "f360_satdec_encode_sample_frames: bad arguments");
+  F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
+                   source_height >= 2 && target_linesize >= 4 * target_width &&
+                   source_linesize >= 1,
+               "f360_satdec_encode_sample_frames: bad geometry");
+  F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}),
+               "f360_satdec_encode_sample_frames: a dimension exceeds 65536");
+  f360_ctx *ctx = dec->ctx;
+  bool one_pass = ctx->opt_fuse_walk != 0 &&
+                  f360::sat_encode_sample_applies(ctx, count, source_width, source_height,
+                                                  source_linesize, target_width, target_height,
+                                                  target_linesize);
+  for (int k = 0; k < count && one_pass; ++k)
+    one_pass = targets_dev[k] && sats_dev[k] && sources_dev[k] &&
+               ((uintptr_t)sources_dev[k] % 16) == 0 && ((uintptr_t)sats_dev[k] % 16) == 0 &&
+               ((uintptr_t)targets_dev[k] % 4) == 0 && std::fabs(centers_xy[2 * k]) <= 16.0f &&
+               std::fabs(centers_xy[2 * k + 1]) <= 16.0f;
+  if (one_pass) {
+    F360_BIND_DEVICE(ctx);
+    if (!dec->gx_dev.p) {
+      int st = f360_satdec_initialize_grid(dec, target_width, target_height, source_width,
+                                           source_height);
+      if (st != F360_OK) return st;
+    }
+    F360_REQUIRE(dec->gw == target_width && dec->gh == target_height,
+                 "f360_satdec_encode_sample_frames: grid was initialised for %dx%d", dec->gw,
+                 dec->gh);
+    // the row plan's reasoning (sat_encode.hip: walk_fuse_plan_kernel) and its packed fields
+    auto increasing = [](const std::vector<int16_t> &g, int max_step) {
+      for (size_t k = 1; k < g.size(); ++k)
+        if (g[k] <= g[k - 1] || g[k] - g[k - 1] > max_step) return false;
+      return true;
+    };
+    one_pass = increasing(dec->gx_host, 1 << 20) && increasing(dec->gy_host, 1023);
+  }
+  if (one_pass) {
+    F360_BIND_DEVICE(ctx);
+    const f360::SatFuse fuse{targets_dev, centers_xy, dec->gx_dev.as<int16_t>(),
+                             dec->gy_dev.as<int16_t>(), target_width, target_height,
+                             target_linesize};
+    return f360::sat_encode_sample_walk(ctx, count, sats_dev, sources_dev, source_width,
+                                        source_height, source_linesize, fuse,
+                                        f360::take_profile_slot(ctx));
+  }
+  int st = f360_sat_encode_batch(ctx, count, sats_dev, sources_dev, source_width, source_height,
+                                 source_linesize);
+  if (st != F360_OK) return st;
+  return f360_satdec_sample_rect_frames(dec, targets_dev, count, target_width, target_height,
+                                        target_linesize, sats_dev, source_width, source_height,
+                                        centers_xy);
 }
 
 }  // extern "C"

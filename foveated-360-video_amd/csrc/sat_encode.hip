@@ -921,21 +921,281 @@ __device__ __forceinline__ void walk_alone_load_batch(const EncodeArgs &a, const
   }
 }
 
-template <int SRC, int DEPTH>
-__global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeArgs a,
-                                                                       const WalkBatch wb) {
+// ---- encode + sample in one pass (f360_satdec_encode_sample_frames) ---------------------------
+// The gaze of every frame is known before its table is built (the server loop receives it before
+// it encodes, src/video_server.cc:287-345), and a strip owner has, at every table row, the whole
+// row of its strip in registers.  A reduced pixel is a box of the table,
+//   (S[hi_y][hi_x] - S[lo_y][hi_x]) - (S[hi_y][lo_x] - S[lo_y][lo_x])) / area
+// (src/sat_decoder_sample_rect_kernel.cl:206-217), so a strip that keeps a copy of its table row
+// at row lo_y ("snapshot") can, at row hi_y, form D = row - snapshot and emit every reduced pixel
+// whose two columns lie inside the strip: (D[hi_x] - D[lo_x]) / area.  The table is written
+// exactly as before; what disappears is the sampler's pass over it (197 of its 233 MB per 8K
+// frame are table rows read back).  Which rows snapshot and which emit is a per-frame row plan
+// (walk_fuse_plan_kernel); which columns a strip owns it works out itself when it starts.  The
+// pixels this leaves out -- boxes that straddle two strips (three per strip boundary at most),
+// and reduced rows whose boxes overlap their neighbours' at the frame's top and bottom edge --
+// are sampled from the finished table by walk_fuse_fix_kernel.
+constexpr uint32_t kFuseEmit = 1u << 31;  // row plan: this table row is the lower edge of a
+                                          // reduced row (bits 0-15: which, bits 16-25: box height)
+constexpr uint32_t kFuseSnap = 1u << 30;  // row plan: snapshot this table row (after emitting)
+#ifndef F360_FUSE_OWNERS
+#define F360_FUSE_OWNERS 4
+#endif
+#ifndef F360_FUSE_HELPERS
+#define F360_FUSE_HELPERS 1
+#endif
+constexpr int kFuseHelpers = F360_FUSE_HELPERS;  // helper waves per strip owner (rows r = h mod kFuseHelpers)
+constexpr int kFuseOwners = F360_FUSE_OWNERS;  // strip owners per workgroup of the one-pass kernel (+ as many helpers)
+constexpr int kFuseEntries = 3 * kStripPx;  // reduced pixels a strip can own: <= 256 per wrap class
+constexpr int kFuseWaveDwords = kFuseEntries + kRowUnroll * 3 * kStripPx;  // + a D row per batch row
+
+struct WalkFuse {
+  uint8_t *dst[kWalkFrames];
+  int cxp[kWalkFrames], cyp[kWalkFrames];
+  const int16_t *gx, *gy;
+  uint32_t *rowplan;  // [frame][plan_stride]
+  int plan_stride, out_w, out_h, dst_linesize;
+  // boxes that straddle two strips: the list per frame ({count, then i, hi, lo per pixel}) and,
+  // per emitted reduced row, the D values of their two columns ([row][pixel][hi | lo][3])
+  uint32_t *spix, *side;
+  int pmax;
+  size_t side_stride;  // dwords per frame
+};
+constexpr int kFixCols = 256;  // straddling pixels of a frame: <= 3 per strip boundary
+constexpr int kSpixWords = 1024;  // 1 + 3 * kFixCols, rounded up; the tail: reduced rows the walk
+constexpr int kSpixLrows = 800;   // cannot emit ({count, rows}), at most kFixLrows listed
+constexpr int kFixLrows = 16;
+struct WalkNoFuse {};
+template <bool FUSE> struct WalkFuseArg { typedef WalkNoFuse type; };
+template <> struct WalkFuseArg<true> { typedef WalkFuse type; };
+
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+// Three bytes of a reduced pixel (the fourth is not ours, sat_decoder_sample_rect_kernel.cl:212),
+// hidden from the compiler's vmcnt bookkeeping like the table stores.
+__device__ __forceinline__ void fuse_store_rgb(uint8_t *row, uint32_t off, uint32_t rg,
+                                               uint32_t b) {
+  asm volatile(
+      "global_store_short %0, %1, %3 nt\n\t"
+      "global_store_byte %0, %2, %3 offset:2 nt" ::"v"(off), "v"(rg), "v"(b), "s"(row)
+      : "memory");
+}
+
+// The three quotients of one box, exact; operands of 2^22 and more (boxes of > 16k pixels) take
+// the integer division inline -- a call would cost the walker its register allocation.
+__device__ __forceinline__ uint3 fuse_div3(uint3 n, uint32_t d) {
+  if (((n.x | n.y | n.z | d) >> 22) != 0) return make_uint3(n.x / d, n.y / d, n.z / d);
+  const float inv = __builtin_amdgcn_rcpf((float)d);
+  return make_uint3(f360::udiv_by_rcp(n.x, inv, d), f360::udiv_by_rcp(n.y, inv, d),
+                    f360::udiv_by_rcp(n.z, inv, d));
+}
+
+// The helper wave of strip owner `unit`: the reduced pixels whose box lies inside the strip --
+// {hi column : 8 | lo column : 8 | reduced column : 16}, worked out once -- and then, batch by
+// batch, for every row the plan marks EMIT: wait for the owner's D row in slot r (mailbox word r
+// = the plan word), one pixel per lane and round, hand the slot back.  The helper waits for
+// nothing but its owner, and the owner only ever waits for a slot of the batch before.
+//
+// A row must take the helper less than the owner takes over its own (~0.45 us), so the first
+// kFuseRounds * 64 pixels of the strip (all of them, outside pathological geometries) live in
+// registers as LDS offsets, and a row's gathers are all issued before the first is used: one
+// LDS round trip per row, not two per round.  Quotients: n <= 255 * area and q = n / area <= 255,
+// so for area <= 2048 the float product n * (1/width) * (1/height), biased by 2^-12, truncates
+// to q exactly -- every rounding together moves it by < 2^-13, a true fraction is at least
+// 1/2048 below the next integer (tests/test_fuse_div.py walks every case); larger boxes divide.
+constexpr int kFuseRounds = 5;
+
+template <int NR>
+__device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFuse &wf,
+                                               const uint32_t *plan, uint8_t *dst, int lane,
+                                               const uint32_t *ent, int n_ent,
+                                               const uint32_t *drows, uint32_t mbox,
+                                               uint32_t max_dxw, const int (&xcol)[3],
+                                               const int (&xslot)[3], int npix, uint32_t *side,
+                                               int which) {
+  const bool exports = __any(xslot[0] >= 0 || xslot[1] >= 0 || xslot[2] >= 0);
+  // this lane's pixel of round k: D-row byte offsets of its two columns, box width, target
+  uint32_t eoff[NR], estore[NR];
+  float einv[NR];
+  bool valid[NR], unit_wide[NR];  // (unit_wide: every pixel of the round is one column wide)
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int e = lane + 64 * k;
+    valid[k] = e < n_ent;
+    const uint32_t en = valid[k] ? ent[e] : 0x00000100u;  // (hi 0, lo 1: width taken as 1 below)
+    const uint32_t hi = en & 255u, lo = (en >> 8) & 255u;
+    const uint32_t dxw = valid[k] ? hi - lo : 1u;
+    eoff[k] = (hi * 12u) | ((lo * 12u) << 12) | (dxw << 24);
+    estore[k] = (en >> 16) * 4u;
+    einv[k] = __builtin_amdgcn_rcpf((float)dxw);
+    unit_wide[k] = __all(dxw == 1u);
+  }
+  for (int t = 0; t < a.walk_nbatches; ++t) {
+    const uint32_t pv = plan[t * kRowUnroll + (lane & (kRowUnroll - 1))];
+    for (int r = 0; r < kRowUnroll; ++r) {
+      const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)pv, r);
+      if (!(pr & kFuseEmit) || (kFuseHelpers > 1 && r % kFuseHelpers != which)) continue;
+#ifndef F360_FUSE_SLEEP
+#define F360_FUSE_SLEEP 1
+#endif
+      while (lds_read_b32(mbox + r * 4) != pr) __builtin_amdgcn_s_sleep(F360_FUSE_SLEEP);
+      const uint32_t dy = (pr >> 16) & 0x3ffu;
+      uint8_t *orow = dst + (size_t)(pr & 0xffffu) * wf.dst_linesize;
+      const uint32_t *d = drows + r * (3 * kStripPx);
+      const char *db = reinterpret_cast<const char *>(d);
+      if (!(a.ablate & 512)) {
+        uint3 n[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const uint32_t *ph = reinterpret_cast<const uint32_t *>(db + (eoff[k] & 0xfffu));
+          const uint32_t *pl = reinterpret_cast<const uint32_t *>(db + ((eoff[k] >> 12) & 0xfffu));
+          n[k] = make_uint3(ph[0] - pl[0], ph[1] - pl[1], ph[2] - pl[2]);
+        }
+        if (dy * max_dxw <= 2048u) {
+          const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            if (dy == 1u && unit_wide[k]) {  // the fovea: a reduced pixel IS a source pixel
+              if (valid[k]) fuse_store_rgb(orow, estore[k], n[k].x | (n[k].y << 8), n[k].z);
+              continue;
+            }
+            const float inv = einv[k] * inv_dy;
+            const uint32_t qx = (uint32_t)__builtin_fmaf((float)n[k].x, inv, 0x1p-12f);
+            const uint32_t qy = (uint32_t)__builtin_fmaf((float)n[k].y, inv, 0x1p-12f);
+            const uint32_t qz = (uint32_t)__builtin_fmaf((float)n[k].z, inv, 0x1p-12f);
+            if (valid[k]) fuse_store_rgb(orow, estore[k], qx | (qy << 8), qz);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const uint3 q = fuse_div3(n[k], (eoff[k] >> 24) * dy);
+            if (valid[k]) fuse_store_rgb(orow, estore[k], (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
+          }
+        }
+        for (int e = lane + 64 * NR; e < n_ent; e += 64) {  // (NR == kFuseRounds only)
+          const uint32_t en = ent[e];
+          const uint32_t hi = en & 255u, lo = (en >> 8) & 255u;
+          const uint32_t *ph = d + hi * 3, *pl = d + lo * 3;
+          const uint3 q = fuse_div3(make_uint3(ph[0] - pl[0], ph[1] - pl[1], ph[2] - pl[2]),
+                                    (hi - lo) * dy);
+          fuse_store_rgb(orow, (en >> 16) * 4, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
+        }
+      }
+      if (exports) {  // this strip's columns of the boxes that straddle two strips
+        uint32_t *srow = side + (size_t)(pr & 0xffffu) * npix * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (xslot[k] >= 0) {
+            const uint32_t *pd = d + xcol[k] * 3;
+            uint32_t *ps = srow + xslot[k] * 3;
+            ps[0] = pd[0];
+            ps[1] = pd[1];
+            ps[2] = pd[2];
+          }
+      }
+      // (the stores above took their data from the D row: every read of it has returned)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(mbox + r * 4), "v"(0u)
+                   : "memory");
+    }
+  }
+}
+
+__device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const WalkFuse &wf,
+                                                 int unit, int lane, uint32_t *ent,
+                                                 uint32_t *box, int which) {
+  const int f = unit / a.nstrips;
+  const int strip = unit - f * a.nstrips;
+  const uint32_t *drows = ent + kFuseEntries;
+  const uint32_t mbox = (uint32_t)reinterpret_cast<uintptr_t>(box);
+  const uint32_t *plan = wf.rowplan + (size_t)f * wf.plan_stride;
+  uint8_t *dst = wf.dst[f];
+  const int cxp = wf.cxp[f];
+  int n_ent = 0;
+  uint32_t max_dxw = 1;
+  for (int i0 = 0; i0 < wf.out_w; i0 += 64) {
+    const int i = i0 + lane, ic = min(i, wf.out_w - 1);
+    const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[ic + 1], wf.gx[ic], a.width, true);
+    const bool own = i < wf.out_w && bx.ok && (bx.hi >> 8) == strip && (bx.lo >> 8) == strip;
+    const unsigned long long m = __ballot(own);
+    if (own) {
+      ent[n_ent + __popcll(m & ((1ull << lane) - 1))] =
+          (uint32_t)(bx.hi & 255) | ((uint32_t)(bx.lo & 255) << 8) | ((uint32_t)i << 16);
+      max_dxw = max(max_dxw, (uint32_t)(bx.hi - bx.lo));
+    }
+    n_ent += __popcll(m);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) max_dxw = max(max_dxw, (uint32_t)__shfl_xor((int)max_dxw, off, 64));
+  max_dxw = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_dxw);
+  // the straddling boxes with a column in this strip: lane, round -> {column, slot in the row}
+  const uint32_t *sp = wf.spix + (size_t)f * kSpixWords;
+  int npix = (int)sp[0];
+  if (npix > wf.pmax) npix = 0;  // (more than the side rows hold: the fix-up takes every row)
+  int xcol[3], xslot[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int q = lane + 64 * k;
+    xcol[k] = 0;
+    xslot[k] = -1;
+    if (q < npix) {
+      const int hi = (int)sp[2 + 3 * q], lo = (int)sp[3 + 3 * q];
+      if ((hi >> 8) == strip) {
+        xcol[k] = hi & 255;
+        xslot[k] = 2 * q;
+      } else if ((lo >> 8) == strip) {
+        xcol[k] = lo & 255;
+        xslot[k] = 2 * q + 1;
+      }
+    }
+  }
+  uint32_t *side = wf.side + (size_t)f * wf.side_stride;
+#define F360_FUSE_ROWS(NR)                                                                  \
+  walk_fuse_rows<NR>(a, wf, plan, dst, lane, ent, n_ent, drows, mbox, max_dxw, xcol, xslot, \
+                     npix, side, which)
+  if (n_ent <= 64) F360_FUSE_ROWS(1);
+  else if (n_ent <= 128) F360_FUSE_ROWS(2);
+  else if (n_ent <= 192) F360_FUSE_ROWS(3);
+  else if (n_ent <= 256) F360_FUSE_ROWS(4);
+  else F360_FUSE_ROWS(kFuseRounds);
+#undef F360_FUSE_ROWS
+}
+
+template <int SRC, int DEPTH, bool FUSE = false>
+__global__ __launch_bounds__(FUSE ? 64 * (1 + kFuseHelpers) * kFuseOwners : 64 * kWalkWaves) void sat_walk_kernel(
+    const EncodeArgs a, const WalkBatch wb, const typename WalkFuseArg<FUSE>::type wf) {
+  constexpr int OW = FUSE ? kFuseOwners : kWalkWaves;  // strip owners per workgroup
   // one LDS object: the waves' 3 KiB store-staging slices, then the workgroup's ticket
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kWalkWaves * 3 * kStripPx + 4];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[OW * 3 * kStripPx + 4];
+  // encode + sample: per strip owner the reduced pixels it owns, the D rows of the current
+  // batch, and the mailbox through which the owner hands them to its helper wave
+  __shared__ __attribute__((aligned(16))) uint32_t fuse_lds[FUSE ? OW * kFuseWaveDwords : 4];
+  __shared__ uint32_t fuse_box[FUSE ? OW * kRowUnroll : 4];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  uint32_t *wg_ticket = stage + kWalkWaves * 3 * kStripPx;
+  // encode + sample: waves OW.. are helpers -- helper k turns the D rows of strip owner
+  // k into reduced pixels while the owner walks on (its SIMD has issue slots to spare: the
+  // owner alone uses a quarter of them)
+  const bool helper = FUSE && (int)(threadIdx.x >> 6) >= OW;
+  const int wave = (threadIdx.x >> 6) & (OW - 1);
+  uint32_t *wg_ticket = stage + OW * 3 * kStripPx;
   if (threadIdx.x == 0)
     *wg_ticket = __hip_atomic_fetch_add(&a.walk->ticket, 1u, __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT);
+  if (FUSE && threadIdx.x < OW * kRowUnroll) fuse_box[threadIdx.x] = 0;
   __syncthreads();
   const unsigned long long serial = a.walk->serial;  // written by the previous launch
   const int unit =
-      __builtin_amdgcn_readfirstlane((int)(*wg_ticket * (uint32_t)kWalkWaves) + wave);
+      __builtin_amdgcn_readfirstlane((int)(*wg_ticket * (uint32_t)OW) + wave);
+  if constexpr (FUSE) {
+#ifdef F360_FUSE_PRIO
+    if (!helper) __builtin_amdgcn_s_setprio(3);
+#endif
+    if (helper) {
+      if (unit < a.walk_units)
+        walk_fuse_helper(a, wf, unit, lane, fuse_lds + wave * kFuseWaveDwords,
+                         fuse_box + wave * kRowUnroll, (int)(threadIdx.x >> 6) / OW - 1);
+      return;
+    }
+  }
   if (unit < a.walk_units) {
     const int f = unit / a.nstrips;
     const int strip = unit - f * a.nstrips;
@@ -967,6 +1227,17 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 0;
     uint32_t slow_polls = 0, spun = 0;  // hand-off waits that took the slow path, their polls
+    // encode + sample: the table row at the last snapshot; D rows and their mailbox (LDS)
+    uint32_t snap[12];
+    const uint32_t dbase =
+        (uint32_t)reinterpret_cast<uintptr_t>(fuse_lds + wave * kFuseWaveDwords + kFuseEntries);
+    const uint32_t mbox = (uint32_t)reinterpret_cast<uintptr_t>(fuse_box + wave * kRowUnroll);
+    const uint32_t *plan = nullptr;
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) snap[e] = 0;
+      plan = wf.rowplan + (size_t)f * wf.plan_stride;
+    }
     const unsigned long long t_start = (a.ablate & 256) ? __builtin_amdgcn_s_memrealtime() : 0;
     const unsigned long long c_start = (a.ablate & 256) ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -1003,7 +1274,8 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
     };
     // write: the table rows (sat_write_kernel's row step with the scans already done)
     auto write_batch = [&](const RowBatch<SRC> &raw, const uint32_t (&inc_rg)[kRowUnroll],
-                           const uint32_t (&inc_b)[kRowUnroll], uint32_t lin, int t) {
+                           const uint32_t (&inc_b)[kRowUnroll], uint32_t lin, int t,
+                           const u32x8 &pw) {
       const int y = t * kRowUnroll;
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r) {
@@ -1044,6 +1316,28 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
           if (base + off < row_dwords && !no_stores)  // width % 4 == 0 -> whole 16 B in range
             global_store_b128_uncounted_nt(row + base + off, q[k]);
         }
+        if constexpr (FUSE) {
+          const uint32_t pr = pw[r];  // wave-uniform (scalar registers)
+          if (pr & kFuseEmit) {
+            // D = this row - snapshot into slot r, once the helper is done with the slot's
+            // previous row (a batch ago), then the plan word into the mailbox: the payload is
+            // in LDS before its flag (one wave's LDS operations execute in order)
+            while (lds_read_b32(mbox + r * 4) != 0) __builtin_amdgcn_s_sleep(1);
+            const uint32_t da = dbase + (uint32_t)r * (3 * kStripPx * 4) + lane * 48;
+            lds_write_b128(da, u32x4{acc[0] - snap[0], acc[1] - snap[1], acc[2] - snap[2],
+                                     acc[3] - snap[3]});
+            lds_write_b128(da + 16, u32x4{acc[4] - snap[4], acc[5] - snap[5], acc[6] - snap[6],
+                                          acc[7] - snap[7]});
+            lds_write_b128(da + 32, u32x4{acc[8] - snap[8], acc[9] - snap[9],
+                                          acc[10] - snap[10], acc[11] - snap[11]});
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(mbox + r * 4), "v"(pr)
+                         : "memory");
+          }
+          if (pr & kFuseSnap) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) snap[e] = acc[e];
+          }
+        }
       }
     };
     // The sums of rows [8t, 8t + 8) over all strips to the left, recomputed from the source with
@@ -1066,6 +1360,13 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
     // the chain would have delivered.
     auto walk_batch = [&](const RowBatch<SRC> &raw, unsigned long long g, int t) {
       uint32_t inc_rg[kRowUnroll], inc_b[kRowUnroll];
+      // encode + sample: the plan words of the batch's rows, a scalar load hidden from the
+      // compiler like every other memory operation of this loop; waited for before the rows
+      u32x8 pw = {0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (FUSE) {
+        const uint32_t *pp = plan + (size_t)t * kRowUnroll;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(pw) : "s"(pp));
+      }
       const uint32_t tot = scan_batch(raw, inc_rg, inc_b);
       uint32_t lin = 0;
       if (need) {
@@ -1082,7 +1383,8 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
       }
       // out to the right BEFORE the heavy part: the chain advances at hand-off latency
       publish(t, lin, tot);
-      write_batch(raw, inc_rg, inc_b, lin, t);
+      if constexpr (FUSE) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pw));
+      write_batch(raw, inc_rg, inc_b, lin, t, pw);
     };
 
     // DEPTH batches of 8 rows rotate through static buffers, DEPTH - 1 of them in flight.  The
@@ -1120,7 +1422,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
   }
   // retire: the last wave of the launch re-arms the state for the next one
   if (lane == 0) {
-    const uint32_t waves = gridDim.x * kWalkWaves;
+    const uint32_t waves = gridDim.x * OW;
     const uint32_t before = __hip_atomic_fetch_add(&a.walk->done, 1u, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
     if (before == waves - 1) {
@@ -1130,6 +1432,137 @@ __global__ __launch_bounds__(64 * kWalkWaves) void sat_walk_kernel(const EncodeA
       __hip_atomic_store(&a.walk->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&a.walk->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+}
+
+// The row plan of encode + sample, one workgroup per frame.  Reduced row j is the box of table
+// rows (lo, hi] (fov_maps.h: sample_axis); with the grid's offsets strictly increasing -- checked
+// on the host -- lo and hi are non-decreasing in j and lo(j + 1) = hi(j) everywhere except where
+// the clamps of sat_decoder_sample_rect_kernel.cl:201-204 bite, next to the frame's top and
+// bottom edge.  A strip owner keeps ONE snapshot, so row j can be emitted by the walk iff
+//   * no processed row snapshots strictly inside (lo, hi): with lo non-decreasing only the rows
+//     just below can, and
+//   * no earlier reduced row already emits at table row hi (two reduced rows clamped onto the
+//     frame's last table row).
+// Such rows get their marks -- EMIT | j | height at hi, SNAP at lo -- and every other processed
+// row is left to walk_fuse_fix_kernel, which recognises it by the missing mark.
+__global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__restrict__ gy,
+                                                             int out_h, int src_w, int src_h,
+                                                             uint32_t *__restrict__ rowplan,
+                                                             int plan_stride,
+                                                             const WalkFuse wf) {
+  uint32_t *plan = rowplan + (size_t)blockIdx.x * plan_stride;
+  uint32_t *sp = wf.spix + (size_t)blockIdx.x * kSpixWords;
+  const int cyp = wf.cyp[blockIdx.x];
+  __shared__ int count, nleft;
+  if (threadIdx.x == 0) count = nleft = 0;
+  for (int y = threadIdx.x; y < plan_stride; y += 256) plan[y] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < out_h; j += 256) {
+    const f360::AxisBox b = f360::sample_axis(cyp, gy[j + 1], gy[j], src_h, false);
+    if (!b.ok) continue;
+    bool fused = true;
+    for (int d = 1; d <= 3; ++d) {
+      if (j + d < out_h) {
+        const f360::AxisBox n = f360::sample_axis(cyp, gy[j + d + 1], gy[j + d], src_h, false);
+        if (n.ok && n.lo > b.lo && n.lo < b.hi) fused = false;
+      }
+      if (j - d >= 0) {
+        const f360::AxisBox p = f360::sample_axis(cyp, gy[j - d + 1], gy[j - d], src_h, false);
+        if (p.ok && p.hi == b.hi) fused = false;
+      }
+    }
+    if (fused) {
+      atomicOr(&plan[b.hi], kFuseEmit | (uint32_t)j | ((uint32_t)(b.hi - b.lo) << 16));
+      atomicOr(&plan[b.lo], kFuseSnap);
+    } else {
+      const int k = atomicAdd(&nleft, 1);
+      if (k < kFixLrows) sp[kSpixLrows + 1 + k] = (uint32_t)j;
+    }
+  }
+  // the reduced columns whose box straddles two strips (in any order: the position in this
+  // list is the pixel's slot in the side rows, for the helpers and for the fix-up alike)
+  const int cxp = wf.cxp[blockIdx.x];
+  for (int i = threadIdx.x; i < wf.out_w; i += 256) {
+    const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[i + 1], wf.gx[i], src_w, true);
+    if (bx.ok && (bx.hi >> 8) != (bx.lo >> 8)) {
+      const int k = atomicAdd(&count, 1);
+      if (k < kFixCols) {
+        sp[1 + 3 * k] = (uint32_t)i;
+        sp[2 + 3 * k] = (uint32_t)bx.hi;
+        sp[3 + 3 * k] = (uint32_t)bx.lo;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sp[0] = (uint32_t)count;
+    sp[kSpixLrows] = (uint32_t)nleft;
+  }
+}
+
+// What the strip owners' helpers left out: in the reduced rows they emitted, the pixels whose box
+// straddles two strips, from the D values the two strips' helpers put into the side rows; every
+// processed pixel of the other reduced rows (the plan kernel's comment), from the finished
+// table with sample_rect_kernel's arithmetic (sat_decoder.hip).
+__global__ __launch_bounds__(256) void walk_fuse_fix_kernel(const WalkBatch wb, const WalkFuse wf,
+                                                            int src_w, int src_h) {
+  const int f = blockIdx.y;
+  const int cxp = wf.cxp[f], cyp = wf.cyp[f];
+  const uint32_t *sat = wb.sat[f];
+  uint8_t *dst = wf.dst[f];
+  const uint32_t *plan = wf.rowplan + (size_t)f * wf.plan_stride;
+  const uint32_t *sp = wf.spix + (size_t)f * kSpixWords;
+  const uint32_t *side = wf.side + (size_t)f * wf.side_stride;
+  const int npix = (int)sp[0];
+  const int nleft = (int)sp[kSpixLrows];
+  auto store = [&](int i, int j, uint3 q) {
+    uint8_t *o = dst + (size_t)j * wf.dst_linesize + (size_t)i * 4;
+    __builtin_nontemporal_store((uint16_t)((q.x & 0xffu) | ((q.y & 0xffu) << 8)),
+                                reinterpret_cast<uint16_t *>(o));
+    __builtin_nontemporal_store((uint8_t)q.z, o + 2);
+  };
+  auto from_table = [&](int i, int j, const f360::AxisBox &by) {
+    const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[i + 1], wf.gx[i], src_w, true);
+    if (!bx.ok) return;
+    auto at = [&](int y, int x) {
+      const uint32_t *p = sat + ((size_t)y * src_w + x) * 3;
+      return make_uint3(p[0], p[1], p[2]);
+    };
+    const uint3 br = at(by.hi, bx.hi), tr = at(by.lo, bx.hi), tl = at(by.lo, bx.lo),
+                bl = at(by.hi, bx.lo);
+    store(i, j,
+          f360::udiv3_exact(make_uint3(br.x - tr.x + tl.x - bl.x, br.y - tr.y + tl.y - bl.y,
+                                       br.z - tr.z + tl.z - bl.z),
+                            (uint32_t)((bx.hi - bx.lo) * (by.hi - by.lo))));
+  };
+  // workgroups past the straddling pixels': 256 columns of one listed leftover row each
+  const int nsb = (wf.out_h * wf.pmax + 255) / 256;
+  if ((int)blockIdx.x >= nsb) {
+    const int ncc = (wf.out_w + 255) / 256;
+    const int idx = blockIdx.x - nsb, lr = idx / ncc, i = (idx - lr * ncc) * 256 + threadIdx.x;
+    if (lr >= min(nleft, kFixLrows) || nleft > kFixLrows || npix > wf.pmax || i >= wf.out_w) return;
+    const int j = (int)sp[kSpixLrows + 1 + lr];
+    from_table(i, j, f360::sample_axis(cyp, wf.gy[j + 1], wf.gy[j], src_h, false));
+    return;
+  }
+  // one thread per (reduced row, straddling pixel): no thread waits for more than its own loads
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int j = t / wf.pmax, k = t - j * wf.pmax;
+  if (j >= wf.out_h) return;
+  const f360::AxisBox by = f360::sample_axis(cyp, wf.gy[j + 1], wf.gy[j], src_h, false);
+  if (!by.ok) return;
+  const uint32_t pr = plan[by.hi];
+  const bool emitted = (pr & kFuseEmit) && (int)(pr & 0xffffu) == j && npix <= wf.pmax;
+  if (emitted) {
+    if (k >= npix) return;
+    const uint32_t *v = side + ((size_t)j * npix + k) * 6;
+    const uint32_t area = (sp[2 + 3 * k] - sp[3 + 3 * k]) * (uint32_t)(by.hi - by.lo);
+    store((int)sp[1 + 3 * k], j,
+          f360::udiv3_exact(make_uint3(v[0] - v[3], v[1] - v[4], v[2] - v[5]), area));
+  } else if (nleft > kFixLrows || npix > wf.pmax) {
+    // (more leftover rows than the list holds: this row's pmax threads take the whole row)
+    for (int i = k; i < wf.out_w; i += wf.pmax) from_table(i, j, by);
   }
 }
 
@@ -1402,7 +1835,7 @@ bool walk_wanted(const f360_ctx *ctx, int count, int width) {
 // frames.  The caller has checked the arguments and that every buffer allows 16-byte accesses.
 int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8_t *const *srcs,
                     const f360::YuvPlanes *yuvs, int width, int height, int linesize,
-                    bool prof) {
+                    bool prof, const f360::SatFuse *fuse = nullptr) {
   f360::SatEncodePlan &p = ctx->enc;
   const int nstrips = (width + kStripPx - 1) / kStripPx;
   const int nb = (height + kRowUnroll - 1) / kRowUnroll;
@@ -1427,7 +1860,16 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   // warm up eagerly with the largest geometry and frame count first.
   const size_t gran_bytes = (size_t)per_launch * nstrips * nb * kWalkLanes * 8;
   const size_t chain_bytes = gran_bytes + (size_t)per_launch * nstrips * 32;
-  if (!p.walk_state.p || !p.walk_err_host || chain_bytes > p.walk_chain.bytes) {
+  // encode + sample: a row plan per frame of a launch (one word per table row, whole batches)
+  const int plan_stride = nb * kRowUnroll;
+  const int pmax = std::max(1, std::min(3 * (nstrips - 1), kFixCols));
+  const size_t side_stride = fuse ? (size_t)fuse->out_h * pmax * 6 : 0;  // dwords per frame
+  const size_t plan_words = (size_t)per_launch * plan_stride;
+  const size_t plan_bytes =
+      fuse ? (plan_words + (size_t)per_launch * kSpixWords + (size_t)per_launch * side_stride) * 4
+           : 0;
+  if (!p.walk_state.p || !p.walk_err_host || chain_bytes > p.walk_chain.bytes ||
+      plan_bytes > p.walk_plan.bytes) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     F360_HIP_TRY(hipStreamIsCapturing(ctx->stream, &cap));
     F360_REQUIRE(cap == hipStreamCaptureStatusNone,
@@ -1460,6 +1902,12 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
     int st = p.walk_chain.reserve(chain_bytes);
     if (st != F360_OK) return st;
     F360_HIP_TRY(hipMemsetAsync(p.walk_chain.p, 0, p.walk_chain.bytes, ctx->stream));
+  }
+
+  if (plan_bytes > p.walk_plan.bytes) {
+    if (p.walk_plan.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int st = p.walk_plan.reserve(plan_bytes);
+    if (st != F360_OK) return st;
   }
 
   EncodeArgs a{};
@@ -1498,9 +1946,48 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
     a.walk_units = n * nstrips;
     const dim3 grid((a.walk_units + kWalkWaves - 1) / kWalkWaves);
     const dim3 block(64 * kWalkWaves);
+    if (fuse) {
+      WalkFuse wf;
+      for (int k = 0; k < kWalkFrames; ++k) {
+        const int q = k0 + (k < n ? k : 0);
+        wf.dst[k] = fuse->dsts[q];
+        wf.cxp[k] = (int)(fuse->centers_xy[2 * q] * (float)width);  // sat_decoder_sample_rect_kernel.cl:176-179
+        wf.cyp[k] = (int)(fuse->centers_xy[2 * q + 1] * (float)height);
+      }
+      wf.gx = fuse->gx;
+      wf.gy = fuse->gy;
+      wf.rowplan = p.walk_plan.as<uint32_t>();
+      wf.plan_stride = plan_stride;
+      wf.out_w = fuse->out_w;
+      wf.out_h = fuse->out_h;
+      wf.dst_linesize = fuse->dst_linesize;
+      wf.spix = wf.rowplan + plan_words;
+      wf.side = wf.spix + (size_t)per_launch * kSpixWords;
+      wf.pmax = pmax;
+      wf.side_stride = side_stride;
+      {
+        f360::KernelSpan span(ctx, f360::kWalkFusePlan, prof, n);
+        hipLaunchKernelGGL(walk_fuse_plan_kernel, dim3(n), dim3(256), 0, ctx->stream, wf.gy,
+                           wf.out_h, width, height, wf.rowplan, plan_stride, wf);
+      }
+      {
+        f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
+        hipLaunchKernelGGL((sat_walk_kernel<kSrcRgb0, 2, true>),
+                           dim3((a.walk_units + kFuseOwners - 1) / kFuseOwners),
+                           dim3(64 * (1 + kFuseHelpers) * kFuseOwners), 0, ctx->stream, a, wb, wf);
+      }
+      {
+        f360::KernelSpan span(ctx, f360::kWalkFuseFix, prof, n);
+        hipLaunchKernelGGL(walk_fuse_fix_kernel,
+                           dim3((wf.out_h * pmax + 255) / 256 +
+                                    kFixLrows * ((wf.out_w + 255) / 256), n),
+                           dim3(256), 0, ctx->stream, wb, wf, width, height);
+      }
+      continue;
+    }
     f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
 #define F360_WALK_LAUNCH(SRC)                                                                   \
-  hipLaunchKernelGGL((sat_walk_kernel<SRC, 2>), grid, block, 0, ctx->stream, a, wb)
+  hipLaunchKernelGGL((sat_walk_kernel<SRC, 2>), grid, block, 0, ctx->stream, a, wb, WalkNoFuse{})
     if (yuv_src == kSrcYuvSwsX86)
       F360_WALK_LAUNCH(kSrcYuvSwsX86);
     else if (yuv_src == kSrcYuvSwsC)
@@ -1514,6 +2001,22 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
 }
 
 }  // namespace
+
+// Encode + sample in one pass (f360_satdec_encode_sample_frames, sat_decoder.hip).  False: the
+// read-once encoder would not take this call, or the frames / grid are outside what the strip
+// owners' packed bookkeeping holds; the caller then makes the two calls.
+bool f360::sat_encode_sample_applies(const f360_ctx *ctx, int count, int width, int height,
+                                     int linesize, int out_w, int out_h, int dst_linesize) {
+  return walk_wanted(ctx, count, width) && linesize / width == 4 && width % 4 == 0 &&
+         linesize % 16 == 0 && (size_t)width * height * 3 < ((size_t)1 << 31) &&
+         out_w < 65536 && out_h < 65536 && (width + kStripPx - 1) / kStripPx <= kFixCols / 4 &&
+         dst_linesize % 4 == 0 && dst_linesize >= 4 * out_w;
+}
+int f360::sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats,
+                                 const uint8_t *const *srcs, int width, int height, int linesize,
+                                 const f360::SatFuse &fuse, bool prof) {
+  return sat_encode_walk(ctx, count, sats, srcs, nullptr, width, height, linesize, prof, &fuse);
+}
 
 // Debug: the per-unit statistics of the last read-once launch that ran with debug.ablate bit 8
 // ({start, end} in 100 MHz ticks, slow-path waits | shader cycles << 16, polls spent waiting); returns the unit count.

@@ -218,6 +218,20 @@ int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *target
                                    int target_linesize, const uint32_t *const *sats_dev,
                                    int source_width, int source_height,
                                    const float *centers_xy);
+/* SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for `count` frames whose gaze is
+ * known before the encode, as in the server loop (src/video_server.cc:287-345: the gaze is
+ * received, then the frame is encoded, then sampled): table k of source k AND reduced frame k at
+ * gaze k, byte for byte what f360_sat_encode_batch followed by f360_satdec_sample_rect_frames
+ * write.  With enough frames for the read-once encoder (f360_sat_encode_batch's rule; RGB0
+ * sources) the reduced pixels are produced during the encoder's pass, from table rows still in
+ * registers, and the tables are not read back; otherwise this IS the two calls.  All arrays are
+ * HOST arrays.  Not in the reference. */
+int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                     uint32_t *const *sats_dev,
+                                     const uint8_t *const *sources_dev, int count,
+                                     int target_width, int target_height, int target_linesize,
+                                     int source_width, int source_height, int source_linesize,
+                                     const float *centers_xy);
 /* Fused SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for a gaze that
  * is known before the encode (the reference's offline modes read it from a trace,
  * src/run_satlogrectilinear.cc:926-938): frame -> reduced frame, the same bytes as

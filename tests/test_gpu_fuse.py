@@ -1,0 +1,146 @@
+"""GPU tier: encode + sample in one pass (f360_satdec_encode_sample_frames, sat_walk_kernel<.., true>)
+against the CPU oracle.  The call must leave, byte for byte, what SATEncoder::EncodeFrameGPU
+followed by SATDecoder::SampleFrameRectGPU leave: the whole table of every frame, and in every
+reduced frame the three colour bytes of the processed pixels and nothing else (targets are
+pre-filled).  The strip owners emit the pixels whose box lies inside one strip from table rows
+they still hold; boxes that straddle two strips and the reduced rows at the frame's clamped top
+and bottom edge come from a second kernel reading the finished table -- so the gaze points below
+put the fovea on strip boundaries, on the seam, on and beyond every edge."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GAZES = [(0.5, 0.5), (0.0, 0.0), (1.0, 1.0), (0.65, 0.75), (0.999, 0.001), (0.25, 0.5),
+         (0.5, 0.0), (0.5, 1.0), (-0.3, 0.4), (1.7, 0.5), (0.5, -0.8), (0.5, 2.2), (0.126, 0.874),
+         (0.3333, 0.6667), (0.0039, 0.9961), (0.75, 0.25)]
+
+
+@pytest.fixture
+def walk_ctx(gpu_ctx):
+    gpu_ctx.set_option("sat.walk", 1)
+    yield gpu_ctx
+    gpu_ctx.set_option("sat.walk", -1)
+    gpu_ctx.set_option("fuse.walk", 1)
+
+
+def _run(f360, ctx, oracle, w, h, gazes, seed=300, fill=0xA5, frames=None, tpad=0):
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    n = len(gazes)
+    if frames is None:
+        frames = [oracle.lcg_frame(w, h, seed + k) for k in range(n)]
+    dec = f360.SATDecoder(ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    srcs = [ctx.upload(np.ascontiguousarray(f).reshape(-1)) for f in frames]
+    sats = [ctx.malloc(w * h * 12) for _ in range(n)]
+    tl = 4 * rw + tpad
+    reds = [ctx.malloc(rh * tl) for _ in range(n)]
+    for b in sats:
+        b.fill(0xEE)
+    for b in reds:
+        b.fill(fill)
+    dec.EncodeSampleFramesGPU([b.ptr for b in reds], rw, rh, tl, [b.ptr for b in sats],
+                              [b.ptr for b in srcs], w, h, 4 * w, gazes)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    bad = []
+    for k in range(n):
+        want_sat = oracle.sat_encode(frames[k], w, h, 4 * w)
+        if not np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want_sat):
+            bad.append(("table", k))
+        want = np.full((rh, tl), fill, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, tl, want_sat, w, h, grid, *gazes[k])
+        got = reds[k].copy_to_host(np.uint8, (rh, tl))
+        if not np.array_equal(got, want):
+            rows = np.nonzero((got != want).any(axis=1))[0]
+            cols = np.nonzero((got != want).any(axis=0))[0] // 4
+            bad.append(("reduced", k, gazes[k], int((got != want).sum()), rows[:6].tolist(),
+                        sorted(set(cols.tolist()))[:6]))
+    for b in srcs + sats + reds:
+        b.free()
+    dec.close()
+    return bad
+
+
+@pytest.mark.parametrize("w,h", [(1024, 512), (1920, 1080), (1336, 203), (256, 128), (520, 66),
+                                 (2048, 96)])
+def test_encode_sample_matches_oracle(f360, walk_ctx, oracle, w, h):
+    assert _run(f360, walk_ctx, oracle, w, h, GAZES) == []
+
+
+def test_encode_sample_special_frames(f360, walk_ctx, oracle):
+    """An all-255 frame (largest sums, boxes of 255 exactly), an all-zero one, padded targets."""
+    w, h = 1536, 320
+    frames = [np.full((h, 4 * w), 255, dtype=np.uint8), np.zeros((h, 4 * w), dtype=np.uint8),
+              oracle.lcg_frame(w, h, 9)]
+    assert _run(f360, walk_ctx, oracle, w, h, [(0.5, 0.5), (0.1, 0.9), (0.8, 0.3)], frames=frames,
+                tpad=32, fill=0x3C) == []
+
+
+def test_encode_sample_gaze_sweep(f360, walk_ctx, oracle):
+    """A fine sweep of the gaze across two strip boundaries and both vertical edges."""
+    w, h = 768, 160
+    gazes = [(x / 96.0, y) for x in range(20, 76) for y in (0.02, 0.5, 0.97)]
+    for k in range(0, len(gazes), 24):
+        assert _run(f360, walk_ctx, oracle, w, h, gazes[k:k + 24], seed=k) == []
+
+
+def test_encode_sample_falls_back_to_the_two_calls(f360, gpu_ctx, oracle):
+    """Below the read-once encoder's frame count, and with the switch off, the call is the two
+    calls -- same bytes."""
+    assert _run(f360, gpu_ctx, oracle, 640, 320, GAZES[:3]) == []
+    gpu_ctx.set_option("sat.walk", 1)
+    gpu_ctx.set_option("fuse.walk", 0)
+    try:
+        assert _run(f360, gpu_ctx, oracle, 640, 320, GAZES[:3]) == []
+    finally:
+        gpu_ctx.set_option("sat.walk", -1)
+        gpu_ctx.set_option("fuse.walk", 1)
+
+
+def test_encode_sample_8k_against_the_two_calls(f360, gpu_ctx):
+    """BASELINE's size: 23 frames of 7680x3840 (the smallest batch the read-once encoder takes by
+    itself), Lissajous gaze; tables and reduced frames equal to what the two calls write."""
+    w, h, n = 7680, 3840, 23
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    rng = np.random.default_rng(8)
+    base = rng.integers(0, 256, (h, 4 * w), dtype=np.uint8)
+    dec = f360.SATDecoder(gpu_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    enc = f360.SATEncoder(gpu_ctx)
+    srcs = []
+    for k in range(n):
+        f = np.roll(base, 977 * k, axis=1)
+        if k == 5:
+            f = np.full_like(base, 255)
+        srcs.append(gpu_ctx.upload(f.reshape(-1)))
+    gazes = [(0.5 + 0.45 * np.sin(2 * np.pi * k / 97), 0.5 + 0.35 * np.sin(2 * np.pi * k / 61))
+             for k in range(n)]
+    gazes[3], gazes[4] = (0.0, 0.0), (1.0, 1.0)
+    sats = [gpu_ctx.malloc(w * h * 12) for _ in range(n)]
+    reds_a = [gpu_ctx.malloc(rw * rh * 4) for _ in range(n)]
+    reds_b = [gpu_ctx.malloc(rw * rh * 4) for _ in range(n)]
+    for b in reds_a + reds_b:
+        b.fill(0x5A)
+    enc.EncodeFramesGPU([b.ptr for b in sats], [b.ptr for b in srcs], w, h, 4 * w)
+    dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, 4 * rw, [b.ptr for b in sats], (w, h),
+                            gazes)
+    want_sat_sums = []
+    for k in (0, 5, 22):
+        t = sats[k].copy_to_host(np.uint32, (h, w, 3))
+        want_sat_sums.append((int(t.sum(dtype=np.uint64)), t[-1, -1].tolist(), t[1234, 4321].tolist()))
+    for b in sats:
+        b.fill(0)
+    dec.EncodeSampleFramesGPU([b.ptr for b in reds_b], rw, rh, 4 * rw, [b.ptr for b in sats],
+                              [b.ptr for b in srcs], w, h, 4 * w, gazes)
+    assert gpu_ctx.debug_walk_recoveries() == 0
+    for k in range(n):
+        a = reds_a[k].copy_to_host(np.uint8, (rh, 4 * rw))
+        b = reds_b[k].copy_to_host(np.uint8, (rh, 4 * rw))
+        assert np.array_equal(a, b), f"reduced frame {k} (gaze {gazes[k]}) differs"
+    for idx, k in enumerate((0, 5, 22)):
+        t = sats[k].copy_to_host(np.uint32, (h, w, 3))
+        assert (int(t.sum(dtype=np.uint64)), t[-1, -1].tolist(), t[1234, 4321].tolist()) == \
+            want_sat_sums[idx], f"table {k} differs"
+    for b in srcs + sats + reds_a + reds_b:
+        b.free()
+    dec.close()
