@@ -206,9 +206,12 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="FoveateFrameRectGPU (encode + sample without writing the table) instead "
                          "of the two reference calls")
-    ap.add_argument("--one-pass", choices=["on", "off"], default="off",
-                    help="on: EncodeSampleFramesGPU (tables AND reduced frames from one pass of the "
-                         "read-once encoder; RGB0 sources) instead of EncodeFramesGPU + SampleFramesRectGPU")
+    ap.add_argument("--one-pass", choices=["on", "off"], default="on",
+                    help="on (default): one EncodeSampleFramesGPU call per group of frames -- the "
+                         "tables AND the reduced frames, the reduced pixels produced during the "
+                         "read-once encoder's pass wherever the library can (RGB0 sources, enough "
+                         "frames per call), else the two calls inside the library; off: "
+                         "EncodeFramesGPU + SampleFramesRectGPU from here")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the short untimed-region measurements of the fused / planar variants")
     ap.add_argument("--share-device", action="store_true",
@@ -464,7 +467,8 @@ def main():
         for name, n in c.profile_frames().items():
             frames_of[name] = frames_of.get(name, 0) + n
     kernels = {name: {"avg_us": round(1e3 * ms / n, 2), "launches": n} for name, (ms, n) in prof.items()}
-    encoder = 2 if args.fused else 1 if "sat_walk_kernel" in kernels else 0
+    one_pass_ran = "walk_fuse_fix_kernel" in kernels  # the library took the one-pass form
+    encoder = 2 if args.fused else 3 if one_pass_ran else 1 if "sat_walk_kernel" in kernels else 0
     per_rank = sharding.gather_run(my_elapsed, B, device=dev if args.backend == "nccl" else None,
                                    encoder=encoder, recoveries=recoveries)
     for name, k in kernels.items():  # a batched call's launch covers several frames
@@ -487,7 +491,10 @@ def main():
         # bytes are overhead); the sampler is charged the distinct corners + the reduced frame.
         # In fused mode the writer emits the distinct box corners instead of the table.
         frame_bytes = (w * h * 3) // 2 if yuv else 4 * w * h
-        alg = {"sat_walk_kernel": enc_bytes,
+        # One pass (EncodeSampleFramesGPU): sat_walk_kernel does the sampler's work as well and is
+        # charged the whole path; the row-plan and fix-up kernels around it do none of it.
+        alg = {"sat_walk_kernel": enc_bytes + (smp_bytes if one_pass_ran else 0),
+               "walk_fuse_plan_kernel": 0, "walk_fuse_fix_kernel": 0,
                "sat_write_kernel": frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes,
                "sat_reduce_kernel": 0, "sat_carry_kernel": 0,
                "sample_rect_kernel": smp_bytes}
@@ -505,7 +512,7 @@ def main():
                     pmc = doc
             except Exception:
                 pmc = {}
-        size_key = f"{w}x{h}" + (":yuv420p" if yuv else "")
+        size_key = f"{w}x{h}" + (":yuv420p" if yuv else ":one_pass" if one_pass_ran else "")
 
         def roof_of(name):
             k = kernels[name]
@@ -545,14 +552,19 @@ def main():
             "data": "synthetic" if not args.share_device else "synthetic (REHEARSAL: ranks share GPU 0)",
             "config": {"workload": f"{w}x{h} {'planar YUV 4:2:0' if yuv else 'RGB0'} equirect frames, "
                                    f"{'fused SAT encode + ' if args.fused else 'SAT encode -> '}"
-                                   f"log-rectilinear SAT sample to {rw}x{rh}, "
+                                   f"log-rectilinear SAT sample to {rw}x{rh}"
+                                   f"{' (tables and reduced frames from one pass)' if one_pass_ran else ''}, "
                                    + (f"ONE batch of {args.global_batch} frames per step sharded over "
                                       f"the GPUs in contiguous blocks" if args.global_batch else
                                       f"batch {B} frames per GPU per step")
-                                   + (f" ({fpc} frames per encode call and per sample call)"
+                                   + (f" ({fpc} frames per EncodeSampleFramesGPU call)" if one_pass
+                                      else f" ({fpc} frames per encode call and per sample call)"
                                       if fpc > 1 else "")
                                    + ", Lissajous gaze, inputs resident in HBM",
                        "source": args.source, "fused": bool(args.fused),
+                       "call": ("EncodeSampleFramesGPU" if one_pass else "FoveateFrameRectGPU"
+                                if args.fused else "EncodeFramesGPU + SampleFramesRectGPU"
+                                if fpc > 1 else "EncodeFrameGPU + SampleFrameRectGPU"),
                        "frame": [w, h], "reduced": [rw, rh], "batch_per_gpu": B,
                        "global_batch": args.global_batch or None,
                        "streams_per_gpu": nstreams, "frames_per_call": fpc,
@@ -602,6 +614,25 @@ def main():
                                             "(src/video_server.cc:300,336), 3 steps after the timed "
                                             "region; path_hbm_frac "
                                             f"{path_bytes * ref_value * 1e6 / (w * h) / 1e9 / HBM_PEAK_GBS:.4f}")
+        if world == 1 and one_pass and not args.no_variants:
+            # the two calls on the same frames, outside the timed region
+            def two_calls():
+                for g in range(0, B, fpc):
+                    n = min(fpc, B - g)
+                    encs[0].EncodeFramesGPU(sat_ptr[:n], frame_ptr[g:g + n], w, h, 4 * w)
+                    decs[0].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n], (w, h),
+                                                gazes[g:g + n])
+            two_calls()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                two_calls()
+            torch.cuda.synchronize(dev)
+            two_value = 5 * B * w * h / 1e6 / (time.perf_counter() - t1)
+            line["value_two_calls"] = round(two_value, 1)
+            line["two_calls"] = ("EncodeFramesGPU + SampleFramesRectGPU on the same frames, 5 steps "
+                                 "after the timed region; path_hbm_frac "
+                                 f"{path_bytes * two_value * 1e6 / (w * h) / 1e9 / HBM_PEAK_GBS:.4f}")
         if world == 1 and not args.no_variants and not args.fused and not yuv:
             # Outside the timed region, for information: the same frames through the fused call
             # (same bytes out, no table) and from planar YUV 4:2:0; a few steps each.

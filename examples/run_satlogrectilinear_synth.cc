@@ -78,7 +78,49 @@ int main(int argc, char **argv) {
   cl::Buffer cl_output_buffer(cl_manager.context, CL_MEM_READ_WRITE, cl_output_buffer_size);
 
   uint64_t digest_rect = 0, digest_full = 0, digest_sat = 0;
-  for (int frame = 0; frame < frames; ++frame) {
+  if (mode == "encode_sample_frames") {
+    // the server loop's three steps (gaze known, EncodeFrameGPU, SampleFrameRectGPU,
+    // src/video_server.cc:287-345) for all the frames in ONE call through the class header; the
+    // digests are those of the per-frame loop below.  "sat.walk" 1: the read-once encoder -- and
+    // with it the one-pass form of this call -- whatever the frame count.
+    f360_ctx_set_option(cl_manager.context(), "sat.walk", 1);
+    std::vector<cl::Buffer> sources, tables, outputs;
+    std::vector<cl_mem> src_ptr, sat_ptr, out_ptr;
+    std::vector<float> centers;
+    for (int frame = 0; frame < frames; ++frame) {
+      lcg_fill(rgb_frame, 12345u + (uint32_t)frame);
+      sources.emplace_back(cl_manager.context, CL_MEM_READ_WRITE, source_frame_size);
+      tables.emplace_back(cl_manager.context, CL_MEM_READ_WRITE, sat_buffer_size);
+      outputs.emplace_back(cl_manager.context, CL_MEM_READ_WRITE, cl_output_buffer_size);
+      cl_int ret = cl::copy(cl_manager.command_queue, rgb_frame.data(),
+                            rgb_frame.data() + source_frame_size, sources.back());
+      ret |= cl::copy(cl_manager.command_queue, rect_frame.data(),
+                      rect_frame.data() + cl_output_buffer_size, outputs.back());
+      if (ret != CL_SUCCESS) return EXIT_FAILURE;
+      centers.push_back(frames == 1 ? 0.5f : 0.25f + 0.5f * frame / frames);
+      centers.push_back(0.5f);
+    }
+    for (int frame = 0; frame < frames; ++frame) {
+      src_ptr.push_back(sources[frame]());
+      sat_ptr.push_back(tables[frame]());
+      out_ptr.push_back(outputs[frame]());
+    }
+    sat_decoder.EncodeSampleFramesGPU(frames, out_ptr.data(), reduced_width, reduced_height,
+                                      rect_linesize, sat_ptr.data(), src_ptr.data(),
+                                      source_codec_ctx, linesize, centers.data());
+    clFinish(cl_manager.command_queue());
+    for (int frame = 0; frame < frames; ++frame) {
+      std::vector<uint8_t> out_rect(rect_frame.size());
+      if (cl::copy(cl_manager.command_queue, outputs[frame], out_rect.data(),
+                   out_rect.data() + cl_output_buffer_size) != CL_SUCCESS)
+        return EXIT_FAILURE;
+      digest_rect ^= fnv1a64(out_rect.data(), out_rect.size()) + frame;
+    }
+    std::vector<uint32_t> sat((size_t)width * height * 3);
+    cl::copy(cl_manager.command_queue, tables[0], sat.data(), sat.data() + sat.size());
+    digest_sat = fnv1a64(sat.data(), sat.size() * sizeof(uint32_t));
+  }
+  for (int frame = 0; frame < frames && mode != "encode_sample_frames"; ++frame) {
     lcg_fill(rgb_frame, 12345u + (uint32_t)frame);  // VideoDecoder::GetFrame stand-in
     const float center_x = frames == 1 ? 0.5f : 0.25f + 0.5f * frame / frames;
     const float center_y = 0.5f;

@@ -288,7 +288,7 @@ class Context:
         """(units, 4) uint64 array {start, end, slow waits, polls} of the last read-once encoder
         launch that ran with debug.ablate bit 8 (f360_debug_walk_stats)."""
         import numpy as np
-        out = np.zeros((max_units, 4), dtype=np.uint64)
+        out = np.zeros((max_units, 8), dtype=np.uint64)
         n = lib().f360_debug_walk_stats(self._h, out.ctypes.data_as(c_void_p), max_units)
         if n < 0:
             _check(n)

@@ -938,14 +938,7 @@ __device__ __forceinline__ void walk_alone_load_batch(const EncodeArgs &a, const
 constexpr uint32_t kFuseEmit = 1u << 31;  // row plan: this table row is the lower edge of a
                                           // reduced row (bits 0-15: which, bits 16-25: box height)
 constexpr uint32_t kFuseSnap = 1u << 30;  // row plan: snapshot this table row (after emitting)
-#ifndef F360_FUSE_OWNERS
-#define F360_FUSE_OWNERS 4
-#endif
-#ifndef F360_FUSE_HELPERS
-#define F360_FUSE_HELPERS 1
-#endif
-constexpr int kFuseHelpers = F360_FUSE_HELPERS;  // helper waves per strip owner (rows r = h mod kFuseHelpers)
-constexpr int kFuseOwners = F360_FUSE_OWNERS;  // strip owners per workgroup of the one-pass kernel (+ as many helpers)
+constexpr int kFuseOwners = kWalkWaves;  // strip owners per workgroup of the one-pass kernel, + as many helpers
 constexpr int kFuseEntries = 3 * kStripPx;  // reduced pixels a strip can own: <= 256 per wrap class
 constexpr int kFuseWaveDwords = kFuseEntries + kRowUnroll * 3 * kStripPx;  // + a D row per batch row
 
@@ -981,6 +974,15 @@ __device__ __forceinline__ void fuse_store_rgb(uint8_t *row, uint32_t off, uint3
       : "memory");
 }
 
+// Three consecutive dwords of LDS at a dword-aligned byte address, no wait: the caller issues a
+// row's worth of these and waits once.
+__device__ __forceinline__ void fuse_lds_read3(uint32_t addr, u32x2 &a01, uint32_t &a2) {
+  asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8"
+               : "=&v"(a01), "=&v"(a2)
+               : "v"(addr)
+               : "memory");
+}
+
 // The three quotients of one box, exact; operands of 2^22 and more (boxes of > 16k pixels) take
 // the integer division inline -- a call would cost the walker its register allocation.
 __device__ __forceinline__ uint3 fuse_div3(uint3 n, uint32_t d) {
@@ -1012,7 +1014,7 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
                                                const uint32_t *drows, uint32_t mbox,
                                                uint32_t max_dxw, const int (&xcol)[3],
                                                const int (&xslot)[3], int npix, uint32_t *side,
-                                               int which) {
+                                               int unit) {
   const bool exports = __any(xslot[0] >= 0 || xslot[1] >= 0 || xslot[2] >= 0);
   // this lane's pixel of round k: D-row byte offsets of its two columns, box width, target
   uint32_t eoff[NR], estore[NR];
@@ -1030,27 +1032,57 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
     einv[k] = __builtin_amdgcn_rcpf((float)dxw);
     unit_wide[k] = __all(dxw == 1u);
   }
+  const bool timed = a.ablate & 256;
+  unsigned long long wait_cycles = 0, work_cycles = 0, rows_done = 0;
   for (int t = 0; t < a.walk_nbatches; ++t) {
-    const uint32_t pv = plan[t * kRowUnroll + (lane & (kRowUnroll - 1))];
+    // The plan words of the batch by a scalar load with its own wait: nothing in this loop may
+    // make the compiler wait on the vector memory counter -- the pixel stores are hidden from
+    // it, and a vmcnt(0) for a plan word waits for the stores of the row before as well (that
+    // was 800 of a row's 1600 cycles).
+    u32x8 pw;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(pw)
+                 : "s"(plan + (size_t)t * kRowUnroll)
+                 : "memory");
+    uint32_t pv = 0;
+#pragma unroll
+    for (int r = 0; r < kRowUnroll; ++r) pv = lane == r ? pw[r] : pv;
     for (int r = 0; r < kRowUnroll; ++r) {
       const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)pv, r);
-      if (!(pr & kFuseEmit) || (kFuseHelpers > 1 && r % kFuseHelpers != which)) continue;
-#ifndef F360_FUSE_SLEEP
-#define F360_FUSE_SLEEP 1
-#endif
-      while (lds_read_b32(mbox + r * 4) != pr) __builtin_amdgcn_s_sleep(F360_FUSE_SLEEP);
+      if (!(pr & kFuseEmit)) continue;
+      const unsigned long long c0 = timed ? __builtin_amdgcn_s_memtime() : 0;
+      while (lds_read_b32(mbox + r * 4) != pr) __builtin_amdgcn_s_sleep(1);
+      const unsigned long long c1 = timed ? __builtin_amdgcn_s_memtime() : 0;
       const uint32_t dy = (pr >> 16) & 0x3ffu;
       uint8_t *orow = dst + (size_t)(pr & 0xffffu) * wf.dst_linesize;
       const uint32_t *d = drows + r * (3 * kStripPx);
-      const char *db = reinterpret_cast<const char *>(d);
+      // every gather of the row -- two columns per pixel, the columns to export -- issued
+      // before anything waits: left to the compiler the rounds wait one after the other, and a
+      // row costs five LDS round trips instead of one (1600 against 1100 cycles for 267 boxes)
+      const uint32_t dlds = (uint32_t)reinterpret_cast<uintptr_t>(d);
+      u32x2 h01[NR], l01[NR], x01[3] = {};
+      uint32_t h2[NR], l2[NR], x2[3] = {};
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        fuse_lds_read3(dlds + (eoff[k] & 0xfffu), h01[k], h2[k]);
+        fuse_lds_read3(dlds + ((eoff[k] >> 12) & 0xfffu), l01[k], l2[k]);
+      }
+      if (exports) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)  // (every lane reads -- column 0 if it has nothing to export)
+          fuse_lds_read3(dlds + (uint32_t)xcol[k] * 12u, x01[k], x2[k]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < NR; ++k)
+        asm volatile("" : "+v"(h01[k]), "+v"(h2[k]), "+v"(l01[k]), "+v"(l2[k]));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(x01[k]), "+v"(x2[k]));
       if (!(a.ablate & 512)) {
         uint3 n[NR];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          const uint32_t *ph = reinterpret_cast<const uint32_t *>(db + (eoff[k] & 0xfffu));
-          const uint32_t *pl = reinterpret_cast<const uint32_t *>(db + ((eoff[k] >> 12) & 0xfffu));
-          n[k] = make_uint3(ph[0] - pl[0], ph[1] - pl[1], ph[2] - pl[2]);
-        }
+        for (int k = 0; k < NR; ++k)
+          n[k] = make_uint3(h01[k].x - l01[k].x, h01[k].y - l01[k].y, h2[k] - l2[k]);
         if (dy * max_dxw <= 2048u) {
           const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
 #pragma unroll
@@ -1081,28 +1113,35 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
           fuse_store_rgb(orow, (en >> 16) * 4, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
         }
       }
-      if (exports) {  // this strip's columns of the boxes that straddle two strips
+      if (exports && !(a.ablate & 8192)) {  // this strip's columns of the boxes that straddle two strips
         uint32_t *srow = side + (size_t)(pr & 0xffffu) * npix * 6;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-          if (xslot[k] >= 0) {
-            const uint32_t *pd = d + xcol[k] * 3;
-            uint32_t *ps = srow + xslot[k] * 3;
-            ps[0] = pd[0];
-            ps[1] = pd[1];
-            ps[2] = pd[2];
-          }
+          if (xslot[k] >= 0)
+            asm volatile("global_store_dwordx3 %0, %1, %2" ::"v"((uint32_t)xslot[k] * 12u),
+                         "v"(u32x3v{x01[k].x, x01[k].y, x2[k]}), "s"(srow)
+                         : "memory");
       }
       // (the stores above took their data from the D row: every read of it has returned)
       asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(mbox + r * 4), "v"(0u)
                    : "memory");
+      if (timed) {
+        wait_cycles += c1 - c0;
+        work_cycles += __builtin_amdgcn_s_memtime() - c1;
+        ++rows_done;
+      }
     }
+  }
+  if (timed && lane == 0) {  // debug.ablate bit 8: the helper's half of the unit's statistics
+    ulonglong2 *st = reinterpret_cast<ulonglong2 *>(a.walk_stats + (size_t)unit * 8 + 4);
+    st[0] = make_ulonglong2(wait_cycles, work_cycles);
+    st[1] = make_ulonglong2(rows_done, (unsigned long long)n_ent);
   }
 }
 
 __device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const WalkFuse &wf,
                                                  int unit, int lane, uint32_t *ent,
-                                                 uint32_t *box, int which) {
+                                                 uint32_t *box) {
   const int f = unit / a.nstrips;
   const int strip = unit - f * a.nstrips;
   const uint32_t *drows = ent + kFuseEntries;
@@ -1151,7 +1190,7 @@ __device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const Walk
   uint32_t *side = wf.side + (size_t)f * wf.side_stride;
 #define F360_FUSE_ROWS(NR)                                                                  \
   walk_fuse_rows<NR>(a, wf, plan, dst, lane, ent, n_ent, drows, mbox, max_dxw, xcol, xslot, \
-                     npix, side, which)
+                     npix, side, unit)
   if (n_ent <= 64) F360_FUSE_ROWS(1);
   else if (n_ent <= 128) F360_FUSE_ROWS(2);
   else if (n_ent <= 192) F360_FUSE_ROWS(3);
@@ -1161,7 +1200,7 @@ __device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const Walk
 }
 
 template <int SRC, int DEPTH, bool FUSE = false>
-__global__ __launch_bounds__(FUSE ? 64 * (1 + kFuseHelpers) * kFuseOwners : 64 * kWalkWaves) void sat_walk_kernel(
+__global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sat_walk_kernel(
     const EncodeArgs a, const WalkBatch wb, const typename WalkFuseArg<FUSE>::type wf) {
   constexpr int OW = FUSE ? kFuseOwners : kWalkWaves;  // strip owners per workgroup
   // one LDS object: the waves' 3 KiB store-staging slices, then the workgroup's ticket
@@ -1186,13 +1225,10 @@ __global__ __launch_bounds__(FUSE ? 64 * (1 + kFuseHelpers) * kFuseOwners : 64 *
   const int unit =
       __builtin_amdgcn_readfirstlane((int)(*wg_ticket * (uint32_t)OW) + wave);
   if constexpr (FUSE) {
-#ifdef F360_FUSE_PRIO
-    if (!helper) __builtin_amdgcn_s_setprio(3);
-#endif
     if (helper) {
       if (unit < a.walk_units)
         walk_fuse_helper(a, wf, unit, lane, fuse_lds + wave * kFuseWaveDwords,
-                         fuse_box + wave * kRowUnroll, (int)(threadIdx.x >> 6) / OW - 1);
+                         fuse_box + wave * kRowUnroll);
       return;
     }
   }
@@ -1229,6 +1265,7 @@ __global__ __launch_bounds__(FUSE ? 64 * (1 + kFuseHelpers) * kFuseOwners : 64 *
     uint32_t slow_polls = 0, spun = 0;  // hand-off waits that took the slow path, their polls
     // encode + sample: the table row at the last snapshot; D rows and their mailbox (LDS)
     uint32_t snap[12];
+    uint32_t box_spins = 0;  // polls spent waiting for the helper to hand a D-row slot back
     const uint32_t dbase =
         (uint32_t)reinterpret_cast<uintptr_t>(fuse_lds + wave * kFuseWaveDwords + kFuseEntries);
     const uint32_t mbox = (uint32_t)reinterpret_cast<uintptr_t>(fuse_box + wave * kRowUnroll);
@@ -1322,7 +1359,10 @@ __global__ __launch_bounds__(FUSE ? 64 * (1 + kFuseHelpers) * kFuseOwners : 64 *
             // D = this row - snapshot into slot r, once the helper is done with the slot's
             // previous row (a batch ago), then the plan word into the mailbox: the payload is
             // in LDS before its flag (one wave's LDS operations execute in order)
-            while (lds_read_b32(mbox + r * 4) != 0) __builtin_amdgcn_s_sleep(1);
+            while (lds_read_b32(mbox + r * 4) != 0) {
+              ++box_spins;
+              __builtin_amdgcn_s_sleep(1);
+            }
             const uint32_t da = dbase + (uint32_t)r * (3 * kStripPx * 4) + lane * 48;
             lds_write_b128(da, u32x4{acc[0] - snap[0], acc[1] - snap[1], acc[2] - snap[2],
                                      acc[3] - snap[3]});
@@ -1413,11 +1453,12 @@ __global__ __launch_bounds__(FUSE ? 64 * (1 + kFuseHelpers) * kFuseOwners : 64 *
     if ((a.ablate & 256) && lane == 0) {
       // (two 16-byte stores: 8-byte stores are reserved for the hand-off granules, whose sc1
       // bit the ISA guard checks)
-      ulonglong2 *st = reinterpret_cast<ulonglong2 *>(a.walk_stats + (size_t)unit * 4);
+      ulonglong2 *st = reinterpret_cast<ulonglong2 *>(a.walk_stats + (size_t)unit * 8);
       st[0] = make_ulonglong2(t_start, __builtin_amdgcn_s_memrealtime());
       // (slow waits in 16 bits, above them the shader-clock cycles of the walk: boxes differ)
       st[1] = make_ulonglong2(
-          slow_polls | ((__builtin_amdgcn_s_memtime() - c_start) << 16), spun);
+          slow_polls | ((__builtin_amdgcn_s_memtime() - c_start) << 16),
+          spun | ((unsigned long long)box_spins << 32));
     }
   }
   // retire: the last wave of the launch re-arms the state for the next one
@@ -1518,9 +1559,10 @@ __global__ __launch_bounds__(256) void walk_fuse_fix_kernel(const WalkBatch wb, 
   const int nleft = (int)sp[kSpixLrows];
   auto store = [&](int i, int j, uint3 q) {
     uint8_t *o = dst + (size_t)j * wf.dst_linesize + (size_t)i * 4;
-    __builtin_nontemporal_store((uint16_t)((q.x & 0xffu) | ((q.y & 0xffu) << 8)),
-                                reinterpret_cast<uint16_t *>(o));
-    __builtin_nontemporal_store((uint8_t)q.z, o + 2);
+    // (plain stores: these pixels' neighbours were written long ago, so each one is a partial
+    // write of a cold line -- left in L2 they cost 3.2 us per 8K frame, written through 7.1)
+    *reinterpret_cast<uint16_t *>(o) = (uint16_t)((q.x & 0xffu) | ((q.y & 0xffu) << 8));
+    o[2] = (uint8_t)q.z;
   };
   auto from_table = [&](int i, int j, const f360::AxisBox &by) {
     const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[i + 1], wf.gx[i], src_w, true);
@@ -1859,7 +1901,7 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
   // being captured into a hipGraph, and a captured launch keeps the hand-off buffer's address:
   // warm up eagerly with the largest geometry and frame count first.
   const size_t gran_bytes = (size_t)per_launch * nstrips * nb * kWalkLanes * 8;
-  const size_t chain_bytes = gran_bytes + (size_t)per_launch * nstrips * 32;
+  const size_t chain_bytes = gran_bytes + (size_t)per_launch * nstrips * 64;
   // encode + sample: a row plan per frame of a launch (one word per table row, whole batches)
   const int plan_stride = nb * kRowUnroll;
   const int pmax = std::max(1, std::min(3 * (nstrips - 1), kFixCols));
@@ -1974,7 +2016,7 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
         f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
         hipLaunchKernelGGL((sat_walk_kernel<kSrcRgb0, 2, true>),
                            dim3((a.walk_units + kFuseOwners - 1) / kFuseOwners),
-                           dim3(64 * (1 + kFuseHelpers) * kFuseOwners), 0, ctx->stream, a, wb, wf);
+                           dim3(128 * kFuseOwners), 0, ctx->stream, a, wb, wf);
       }
       {
         f360::KernelSpan span(ctx, f360::kWalkFuseFix, prof, n);
@@ -2027,7 +2069,7 @@ extern "C" int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int
   const int n = std::min(max_units, p.walk_stats_units);
   if (n <= 0 || !p.walk_chain.p) return 0;
   F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  F360_HIP_TRY(hipMemcpy(out, p.walk_chain.as<uint8_t>() + p.walk_stats_offset, (size_t)n * 32,
+  F360_HIP_TRY(hipMemcpy(out, p.walk_chain.as<uint8_t>() + p.walk_stats_offset, (size_t)n * 64,
                          hipMemcpyDeviceToHost));
   return n;
 }

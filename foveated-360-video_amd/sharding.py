@@ -37,7 +37,7 @@ def reduce_run(elapsed_s: float, pixels: float, device=None):
 
 
 ENCODERS = ("three kernels (reduce, carry, write)", "read-once (sat_walk_kernel)",
-            "fused (emit mode)")
+            "fused (emit mode)", "one pass (sat_walk_kernel with helper waves: tables + reduced frames)")
 
 
 def gather_run(elapsed_s: float, frames: int, device=None, encoder: int = 0, recoveries: int = 0):

@@ -394,7 +394,9 @@ int f360_ctx_profile_frames(f360_ctx *ctx, int kernel_id, int *frames);
 int f360_ctx_profile_reset(f360_ctx *ctx);
 /* Debug: per (frame, strip) unit of the last read-once encoder launch that ran with option
  * "debug.ablate" bit 8 set: {start, end} of the unit's wave in 100 MHz ticks, hand-off waits
- * that took the slow path, polls spent in them (4 x 64-bit words per unit, launch order).
+ * that took the slow path, polls spent in them; then, for f360_satdec_encode_sample_frames, the
+ * unit's helper wave: cycles spent waiting for rows, cycles spent on them, rows, boxes (8 x
+ * 64-bit words per unit, launch order).
  * Returns the number of units written (<= max_units), or a negative status. */
 int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int max_units);
 /* Strips of the read-once encoder whose wait for a hand-off ran into its bound ("debug.walk_spin"

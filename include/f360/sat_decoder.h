@@ -101,6 +101,30 @@ class SATDecoder {
                 << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 
+  // Not in the reference: SATEncoder::EncodeFramesGPU + SampleFramesRectGPU for `count` frames
+  // whose gaze is known before the encode, as in the server loop (src/video_server.cc:287-345) --
+  // the same tables and reduced frames; with enough frames for the read-once encoder the reduced
+  // pixels are produced during its pass and the tables are not read back.
+  template <class CodecContext>
+  void EncodeSampleFramesGPU(int count, cl_mem const *cl_target_buffers, int target_width,
+                             int target_height, int target_linesize, cl_mem const *cl_tables,
+                             cl_mem const *cl_source_frames, CodecContext *codec_ctx,
+                             int source_linesize, const float *centers_xy) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::EncodeSampleFramesGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_encode_sample_frames(
+        impl, reinterpret_cast<uint8_t *const *>(cl_target_buffers),
+        reinterpret_cast<uint32_t *const *>(cl_tables),
+        reinterpret_cast<const uint8_t *const *>(cl_source_frames), count, target_width,
+        target_height, target_linesize, codec_ctx->width, codec_ctx->height, source_linesize,
+        centers_xy);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::EncodeSampleFramesGPU] kernel launch failed:" << ret << " "
+                << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
   // Not in the reference: EncodeFrameGPU + SampleFrameRectGPU fused for a gaze known before the
   // encode (its offline modes, src/run_satlogrectilinear.cc:926-938); same bytes, no table.
   void FoveateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,

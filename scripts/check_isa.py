@@ -179,6 +179,22 @@ def main():
                                         f"of the row loop")
                         if not any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in body):
                             perf.append(f"{name}: the row loop has no counted vmcnt wait")
+                # the one-pass encode + sample instantiation: its helper waves' row loops (the
+                # loops that store reduced pixels) must never wait on the vector memory counter
+                # -- the pixel stores are hidden from the compiler, and any vmcnt wait there
+                # also waits for the stores of the row before (it cost 800 cycles per row when a
+                # plan word was read with a vector load)
+                if "sat_walk" in name and "Lb1E" in name:
+                    seen.add("one-pass walker")
+                    px = [[t for _, t, _ in lp] for lp in all_loops(ins)]
+                    px = [lt for lt in px if any(t.startswith("global_store_short") for t in lt)
+                          and not any(t.startswith("global_store_dwordx4") for t in lt)]
+                    if not px:
+                        perf.append(f"{name}: no helper row loop (pixel stores) found")
+                    if any(" nt" not in t for lt in px for t in lt if t.startswith("global_store_short")):
+                        perf.append(f"{name}: helper pixel stores lost their nt bit")
+                    if any("vmcnt" in t for lt in px for t in lt):
+                        perf.append(f"{name}: a vmcnt wait inside a helper row loop")
                 # hipcc 7.2 miscompiles byte packing around this instruction (its upper half is
                 # not zero on gfx950 but later ORs assume so): both times it appeared, the parity
                 # tests failed; the kernels are written so that it is not selected
@@ -199,7 +215,7 @@ def main():
                         perf.append(f"{name}: pixel stores lost their nt bit")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for k in ("writer", "reducer", "streamer", "batch streamer"):
+    for k in ("writer", "reducer", "streamer", "batch streamer", "one-pass walker"):
         if k not in seen:
             perf.append(f"no {k} kernel found in {lib}")
     # the library always exports f360_sat_encode_batch: without a recognised strip walker the

@@ -1,0 +1,83 @@
+"""Soak of the one-pass encode + sample (f360_satdec_encode_sample_frames with the read-once
+encoder forced on) against the two calls it replaces, byte for byte, on random geometries, frame
+counts, gaze points (inside, on and beyond every edge), padded targets:
+    python scripts/fuse_soak.py [seconds] [seed]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import f360_amd as f360
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t0 = time.time()
+calls = frames_done = bad = 0
+worst = []
+with f360.Context(0) as ctx:
+    ctx.set_option("sat.walk", 1)
+    enc = f360.SATEncoder(ctx)
+    while time.time() - t0 < budget:
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            w, h = 4 * int(rng.integers(1, 300)), int(rng.integers(2, 200))
+        elif kind == 1:
+            w, h = 4 * int(rng.integers(200, 1100)), int(rng.integers(2, 120))
+        elif kind == 2:
+            w, h = 4 * int(rng.integers(16, 200)), int(rng.integers(100, 1200))
+        else:
+            w, h = 256 * int(rng.integers(1, 12)), 8 * int(rng.integers(1, 60))
+        n = int(rng.integers(1, 14))
+        rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+        tpad = 4 * int(rng.integers(0, 5))
+        tl = 4 * rw + tpad
+        gazes = []
+        for _ in range(n):
+            m = rng.integers(0, 4)
+            if m == 0:
+                g = (float(rng.uniform(0, 1)), float(rng.uniform(0, 1)))
+            elif m == 1:
+                g = (float(rng.uniform(-1.5, 2.5)), float(rng.uniform(-1.5, 2.5)))
+            elif m == 2:
+                g = (float(rng.choice([0.0, 1.0, 0.5, 1 / w, 1 - 1 / w])), float(rng.choice([0.0, 1.0, 0.5, 1 / h, 1 - 1 / h])))
+            else:  # the fovea on a strip boundary
+                g = (float(np.clip((256 * int(rng.integers(0, max(1, w // 256) + 1)) + int(rng.integers(-2, 3))) / w, -15, 15)),
+                     float(rng.uniform(0, 1)))
+            gazes.append(g)
+        dec = f360.SATDecoder(ctx)
+        dec.InitializeGrid(rw, rh, w, h)
+        fr = rng.integers(0, 256, (n, h, 4 * w), dtype=np.uint8)
+        if rng.integers(0, 8) == 0:
+            fr[0] = 255
+        srcs = [ctx.upload(fr[k].reshape(-1)) for k in range(n)]
+        sats_a = [ctx.malloc(w * h * 12) for _ in range(n)]
+        sats_b = [ctx.malloc(w * h * 12) for _ in range(n)]
+        reds_a = [ctx.malloc(rh * tl) for _ in range(n)]
+        reds_b = [ctx.malloc(rh * tl) for _ in range(n)]
+        fill = int(rng.integers(0, 256))
+        for b in reds_a + reds_b:
+            b.fill(fill)
+        for b in sats_b:
+            b.fill(0xEE)
+        enc.EncodeFramesGPU([b.ptr for b in sats_a], [b.ptr for b in srcs], w, h, 4 * w)
+        dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, tl, [b.ptr for b in sats_a], (w, h), gazes)
+        dec.EncodeSampleFramesGPU([b.ptr for b in reds_b], rw, rh, tl, [b.ptr for b in sats_b],
+                                  [b.ptr for b in srcs], w, h, 4 * w, gazes)
+        for k in range(n):
+            ra, rb = reds_a[k].copy_to_host(np.uint8, (rh, tl)), reds_b[k].copy_to_host(np.uint8, (rh, tl))
+            ta, tb = sats_a[k].copy_to_host(np.uint32, (h, w, 3)), sats_b[k].copy_to_host(np.uint32, (h, w, 3))
+            d = int((ra != rb).sum()) + int((ta != tb).sum())
+            if d:
+                bad += 1
+                if len(worst) < 10:
+                    worst.append((w, h, n, k, gazes[k], tpad, int((ra != rb).sum()), int((ta != tb).sum())))
+        calls += 1
+        frames_done += n
+        for b in srcs + sats_a + sats_b + reds_a + reds_b:
+            b.free()
+        dec.close()
+    rec = ctx.debug_walk_recoveries()
+print({"calls": calls, "frames": frames_done, "differing_frames": bad, "first_failures": worst or None,
+       "handoff_recoveries": rec, "seconds": round(time.time() - t0, 1), "seed": seed})
+sys.exit(1 if bad else 0)

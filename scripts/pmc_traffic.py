@@ -5,7 +5,7 @@ bench.py reports `roofline.traffic` only while that hash matches the tree it run
 
     python scripts/pmc_traffic.py <out.json> <pmc dir(s) with FETCH_SIZE> <pmc dir(s) with WRITE_SIZE> [yuv dirs...]
     (a "dir" may be several directories joined with ':' -- the default command's passes and the
-    one-frame-per-call passes)
+    one-frame-per-call passes; the default command's passes with and without --one-pass)
     python scripts/pmc_traffic.py --hash          # the hash of the current csrc/
 """
 import csv
@@ -65,7 +65,7 @@ def main():
     # an entry is per FRAME (per-launch counters divided by the frames of the launch), bench.py
     # multiplies by the frames its own launches cover.  RGB0 source = 1, LDS-staged stores = 1,
     # ring of 3 slots, byte stores.
-    for inst, kernel, dbl, fpl in (("sat_walk_kernel<1, 2>", "sat_walk_kernel", 2, 32),
+    for inst, kernel, dbl, fpl in (("sat_walk_kernel<1, 2, false>", "sat_walk_kernel", 2, 32),
                                    ("sample_rect_stream_batch_kernel<3>", "sample_rect_kernel", 2, 16),
                                    ("sat_write_kernel<1, 1>", "sat_write_kernel", 2, 1),
                                    ("sat_reduce_kernel<1>", "sat_reduce_kernel", 2, 1),
@@ -79,11 +79,21 @@ def main():
     if len(sys.argv) >= 6:
         yf, yw = means(sys.argv[4], "FETCH_SIZE"), means(sys.argv[5], "WRITE_SIZE")
         # planar source, x86 rounding model = 3
-        for inst, kernel, fpl in (("sat_walk_kernel<3, 2>", "sat_walk_kernel", 32),
+        for inst, kernel, fpl in (("sat_walk_kernel<3, 2, false>", "sat_walk_kernel", 32),
                                   ("sat_write_kernel<3, 1>", "sat_write_kernel", 1),
                                   ("sat_reduce_kernel<3>", "sat_reduce_kernel", 1)):
             if inst in yf and inst in yw:
                 doc.setdefault(kernel, {})[size + ":yuv420p"] = int(1024 * (2 * yf[inst] + yw[inst]) / fpl)
+    # the default command's one-pass kernels (EncodeSampleFramesGPU): the strip walker with helper
+    # waves, its row-plan kernel and the fix-up of the boxes that straddle two strips
+    for inst, kernel, dbl in (("sat_walk_kernel<1, 2, true>", "sat_walk_kernel", 2),
+                              ("walk_fuse_plan_kernel", "walk_fuse_plan_kernel", 1),
+                              ("walk_fuse_fix_kernel", "walk_fuse_fix_kernel", 1)):
+        if inst in fetch and inst in write:
+            e = doc.setdefault(kernel, {})
+            e[size + ":one_pass"] = int(1024 * (dbl * fetch[inst] + write[inst]) / 32)
+            e["_one_pass_fetch_kb"] = round(fetch[inst] / 32, 1)
+            e["_one_pass_write_kb"] = round(write[inst] / 32, 1)
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc))

@@ -2,10 +2,11 @@
 against the CPU oracle.  The call must leave, byte for byte, what SATEncoder::EncodeFrameGPU
 followed by SATDecoder::SampleFrameRectGPU leave: the whole table of every frame, and in every
 reduced frame the three colour bytes of the processed pixels and nothing else (targets are
-pre-filled).  The strip owners emit the pixels whose box lies inside one strip from table rows
-they still hold; boxes that straddle two strips and the reduced rows at the frame's clamped top
-and bottom edge come from a second kernel reading the finished table -- so the gaze points below
-put the fovea on strip boundaries, on the seam, on and beyond every edge."""
+pre-filled).  A strip owner's helper wave emits the pixels whose box lies inside the strip from
+differences of table rows the owner still holds; boxes that straddle two strips are put together
+by a second kernel from the two strips' halves, and the reduced rows at the frame's clamped top
+and bottom edge are sampled from the finished table -- so the gaze points below put the fovea on
+strip boundaries, on the seam, on and beyond every edge."""
 import numpy as np
 import pytest
 
@@ -144,3 +145,111 @@ def test_encode_sample_8k_against_the_two_calls(f360, gpu_ctx):
     for b in srcs + sats + reds_a + reds_b:
         b.free()
     dec.close()
+
+
+def test_encode_sample_many_frames_three_launches(f360, walk_ctx, oracle):
+    """140 frames of two strips: three launches of the one-pass kernel, each with its own row
+    plans and side rows in the shared scratch."""
+    rng = np.random.default_rng(3)
+    gazes = [(float(rng.uniform(-0.2, 1.2)), float(rng.uniform(-0.2, 1.2))) for _ in range(140)]
+    assert _run(f360, walk_ctx, oracle, 512, 64, gazes) == []
+
+
+def test_encode_sample_recarved_and_mixed_with_plain_encodes(f360, walk_ctx, oracle):
+    """The one-pass scratch (plans, side rows) grows with the geometry and is shared with the plain
+    read-once encoder's hand-off buffers: small, large, small again, a plain batched encode in
+    between."""
+    from test_gpu_walk import _encode_batch_and_check
+    assert _run(f360, walk_ctx, oracle, 520, 66, GAZES[:5]) == []
+    assert _run(f360, walk_ctx, oracle, 2048, 96, GAZES[:9]) == []
+    assert _encode_batch_and_check(f360, walk_ctx, oracle, 1024, 64, 6) == []
+    assert _run(f360, walk_ctx, oracle, 520, 66, GAZES[5:12]) == []
+    assert _run(f360, walk_ctx, oracle, 1024, 512, GAZES[:4], seed=77) == []
+
+
+def test_encode_sample_survives_a_missing_hand_off(f360, walk_ctx, oracle):
+    """A strip owner whose hand-off never comes finishes alone (test_gpu_walk.py); its helper wave
+    must neither notice nor wait: same tables, same reduced frames, recoveries counted."""
+    walk_ctx.set_option("debug.walk_mute", 2)
+    walk_ctx.set_option("debug.walk_spin", 64)
+    try:
+        walk_ctx.debug_walk_recoveries()
+        assert _run(f360, walk_ctx, oracle, 1024, 96, GAZES[:3]) == []
+        assert walk_ctx.debug_walk_recoveries() >= 1
+    finally:
+        walk_ctx.set_option("debug.walk_mute", 0)
+        walk_ctx.set_option("debug.walk_spin", 0)
+
+
+def test_cpp_encode_sample_frames_example(f360, gpu_ctx, oracle):
+    """SATDecoder::EncodeSampleFramesGPU through include/f360/sat_decoder.h: the example's digests
+    of the tables / reduced frames equal the oracle's for the per-frame call sequence."""
+    import json
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "examples", "run_satlogrectilinear_synth")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(repo, "examples")], check=True)
+    w, h, n = 768, 192, 6
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    out = subprocess.run([exe, "encode_sample_frames", str(w), str(h), str(n)], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    digest = 0
+    for k in range(n):
+        sat = oracle.sat_encode(oracle.lcg_frame(w, h, 12345 + k), w, h, 4 * w)
+        if k == 0:
+            assert got["sat"] == f"{oracle.fnv1a64(sat):016x}"
+        red = np.full((rh, 4 * rw), 0xA5, dtype=np.uint8)
+        cx = float(np.float32(0.25) + np.float32(0.5) * np.float32(k) / np.float32(n))
+        oracle.satdec_sample_rect(red, rw, rh, 4 * rw, sat, w, h, grid, cx, 0.5)
+        digest ^= (oracle.fnv1a64(red) + k) & 0xFFFFFFFFFFFFFFFF
+    assert got["rect"] == f"{digest:016x}"
+
+
+def test_one_pass_refuses_to_allocate_under_stream_capture(f360, gpu_ctx):
+    """Like the plain read-once encoder: the first call of a geometry allocates (hand-off
+    granules, row plans, side rows) and must say so instead of doing it inside a capture."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h, n = 1024, 128, 4
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        frames = torch.randint(0, 256, (n, h, 4 * w), dtype=torch.uint8, device=dev)
+        sats = torch.zeros((n, h, w, 3), dtype=torch.int32, device=dev)
+        reds = torch.zeros((n, rh, 4 * rw), dtype=torch.uint8, device=dev)
+        want = torch.zeros_like(reds)
+    stream.synchronize()
+    ctx = f360.Context(0, stream=stream.cuda_stream)
+    ctx.set_option("sat.walk", 1)
+    dec = f360.SATDecoder(ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    gazes = [(0.3, 0.6)] * n
+    args = (rw, rh, 4 * rw, [sats[k].data_ptr() for k in range(n)],
+            [frames[k].data_ptr() for k in range(n)], w, h, 4 * w, gazes)
+    g = torch.cuda.CUDAGraph()
+    refused = False
+    with torch.cuda.graph(g, stream=stream):
+        try:
+            dec.EncodeSampleFramesGPU([reds[k].data_ptr() for k in range(n)], *args)
+        except f360.F360Error as e:
+            refused = "captured" in str(e)
+    assert refused
+    stream.synchronize()
+    # warmed up eagerly, the same call is capturable and replays to the same bytes
+    dec.EncodeSampleFramesGPU([want[k].data_ptr() for k in range(n)], *args)
+    ctx.finish()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=stream):
+        dec.EncodeSampleFramesGPU([reds[k].data_ptr() for k in range(n)], *args)
+    for _ in range(3):
+        reds.zero_()
+        g2.replay()
+        stream.synchronize()
+        assert torch.equal(reds, want)
+    dec.close()
+    ctx.close()
