@@ -940,7 +940,8 @@ constexpr uint32_t kFuseEmit = 1u << 31;  // row plan: this table row is the low
 constexpr uint32_t kFuseSnap = 1u << 30;  // row plan: snapshot this table row (after emitting)
 constexpr int kFuseOwners = kWalkWaves;  // strip owners per workgroup of the one-pass kernel, + as many helpers
 constexpr int kFuseEntries = 3 * kStripPx;  // reduced pixels a strip can own: <= 256 per wrap class
-constexpr int kFuseWaveDwords = kFuseEntries + kRowUnroll * 3 * kStripPx;  // + a D row per batch row
+constexpr int kFuseRawRows = kFuseEntries + kRowUnroll * 3 * kStripPx;  // (offset of the pixel rows)
+constexpr int kFuseWaveDwords = kFuseRawRows + kRowUnroll * kStripPx;  // + a D row and a pixel row per batch row
 
 struct WalkFuse {
   uint8_t *dst[kWalkFrames];
@@ -1028,7 +1029,7 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
     const uint32_t hi = en & 255u, lo = (en >> 8) & 255u;
     const uint32_t dxw = valid[k] ? hi - lo : 1u;
     eoff[k] = (hi * 12u) | ((lo * 12u) << 12) | (dxw << 24);
-    estore[k] = (en >> 16) * 4u;
+    estore[k] = ((en >> 16) * 4u) | (hi << 22);  // (reduced column * 4 < 2^18; the hi column again)
     einv[k] = __builtin_amdgcn_rcpf((float)dxw);
     unit_wide[k] = __all(dxw == 1u);
   }
@@ -1062,10 +1063,17 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
       const uint32_t dlds = (uint32_t)reinterpret_cast<uintptr_t>(d);
       u32x2 h01[NR], l01[NR], x01[3] = {};
       uint32_t h2[NR], l2[NR], x2[3] = {};
+      const bool one_row = dy == 1u;
+      const uint32_t plds = (uint32_t)reinterpret_cast<uintptr_t>(
+          drows + kRowUnroll * 3 * kStripPx + r * kStripPx);  // the source pixels of the row
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
-        fuse_lds_read3(dlds + (eoff[k] & 0xfffu), h01[k], h2[k]);
-        fuse_lds_read3(dlds + ((eoff[k] >> 12) & 0xfffu), l01[k], l2[k]);
+        if (one_row && unit_wide[k]) {  // the fovea: a reduced pixel IS a source pixel
+          asm volatile("ds_read_b32 %0, %1" : "=v"(h2[k]) : "v"(plds + (estore[k] >> 22) * 4u) : "memory");
+        } else {
+          fuse_lds_read3(dlds + (eoff[k] & 0xfffu), h01[k], h2[k]);
+          fuse_lds_read3(dlds + ((eoff[k] >> 12) & 0xfffu), l01[k], l2[k]);
+        }
       }
       if (exports) {
 #pragma unroll
@@ -1087,21 +1095,26 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
           const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
-            if (dy == 1u && unit_wide[k]) {  // the fovea: a reduced pixel IS a source pixel
-              if (valid[k]) fuse_store_rgb(orow, estore[k], n[k].x | (n[k].y << 8), n[k].z);
+            if (one_row && unit_wide[k]) {  // R, G from the low half, B from byte 2
+              if (valid[k])
+                asm volatile(
+                    "global_store_short %0, %1, %2 nt\n\t"
+                    "global_store_byte_d16_hi %0, %1, %2 offset:2 nt" ::"v"(estore[k] & 0x3fffffu),
+                    "v"(h2[k]), "s"(orow)
+                    : "memory");
               continue;
             }
             const float inv = einv[k] * inv_dy;
             const uint32_t qx = (uint32_t)__builtin_fmaf((float)n[k].x, inv, 0x1p-12f);
             const uint32_t qy = (uint32_t)__builtin_fmaf((float)n[k].y, inv, 0x1p-12f);
             const uint32_t qz = (uint32_t)__builtin_fmaf((float)n[k].z, inv, 0x1p-12f);
-            if (valid[k]) fuse_store_rgb(orow, estore[k], qx | (qy << 8), qz);
+            if (valid[k]) fuse_store_rgb(orow, estore[k] & 0x3fffffu, qx | (qy << 8), qz);
           }
         } else {
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
             const uint3 q = fuse_div3(n[k], (eoff[k] >> 24) * dy);
-            if (valid[k]) fuse_store_rgb(orow, estore[k], (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
+            if (valid[k]) fuse_store_rgb(orow, estore[k] & 0x3fffffu, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
           }
         }
         for (int e = lane + 64 * NR; e < n_ent; e += 64) {  // (NR == kFuseRounds only)
@@ -1317,12 +1330,9 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r) {
         if (y + r > y_last) break;
-        uint32_t c[12];
-        {
-          uint32_t v[4];
-          batch_pixels<SRC>(a, raw, r, v);
-          unpack_px4(make_uint4(v[0], v[1], v[2], v[3]), c);
-        }
+        uint32_t c[12], px[4];
+        batch_pixels<SRC>(a, raw, r, px);
+        unpack_px4(make_uint4(px[0], px[1], px[2], px[3]), c);
 #pragma unroll
         for (int k = 1; k < 4; ++k) {
           c[3 * k + 0] += c[3 * k - 3];
@@ -1356,6 +1366,10 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
         if constexpr (FUSE) {
           const uint32_t pr = pw[r];  // wave-uniform (scalar registers)
           if (pr & kFuseEmit) {
+            // (a reduced row one table row high: where its boxes are also one column wide --
+            // the fovea -- a reduced pixel is the source pixel itself, so the source row goes
+            // along and saves the helper five LDS reads and three subtractions per pixel)
+            const bool one_row = ((pr >> 16) & 0x3ffu) == 1u;
             // D = this row - snapshot into slot r, once the helper is done with the slot's
             // previous row (a batch ago), then the plan word into the mailbox: the payload is
             // in LDS before its flag (one wave's LDS operations execute in order)
@@ -1370,6 +1384,9 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
                                           acc[7] - snap[7]});
             lds_write_b128(da + 32, u32x4{acc[8] - snap[8], acc[9] - snap[9],
                                           acc[10] - snap[10], acc[11] - snap[11]});
+            if (one_row)
+              lds_write_b128(dbase + (uint32_t)(kRowUnroll * 3 + r) * (kStripPx * 4) + lane * 16,
+                             u32x4{px[0], px[1], px[2], px[3]});
             asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(mbox + r * 4), "v"(pr)
                          : "memory");
           }
