@@ -1162,20 +1162,24 @@ __device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const Walk
   const uint32_t *plan = wf.rowplan + (size_t)f * wf.plan_stride;
   uint8_t *dst = wf.dst[f];
   const int cxp = wf.cxp[f];
+  // (the boxes one column wide first, then the others, each group by reduced column: whole
+  // rounds of the former take the fovea's short cut, and a round's stores stay consecutive)
   int n_ent = 0;
   uint32_t max_dxw = 1;
-  for (int i0 = 0; i0 < wf.out_w; i0 += 64) {
-    const int i = i0 + lane, ic = min(i, wf.out_w - 1);
-    const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[ic + 1], wf.gx[ic], a.width, true);
-    const bool own = i < wf.out_w && bx.ok && (bx.hi >> 8) == strip && (bx.lo >> 8) == strip;
-    const unsigned long long m = __ballot(own);
-    if (own) {
-      ent[n_ent + __popcll(m & ((1ull << lane) - 1))] =
-          (uint32_t)(bx.hi & 255) | ((uint32_t)(bx.lo & 255) << 8) | ((uint32_t)i << 16);
-      max_dxw = max(max_dxw, (uint32_t)(bx.hi - bx.lo));
+  for (int pass = 0; pass < 2; ++pass)
+    for (int i0 = 0; i0 < wf.out_w; i0 += 64) {
+      const int i = i0 + lane, ic = min(i, wf.out_w - 1);
+      const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[ic + 1], wf.gx[ic], a.width, true);
+      const bool own = i < wf.out_w && bx.ok && (bx.hi >> 8) == strip && (bx.lo >> 8) == strip &&
+                       (bx.hi - bx.lo == 1) == (pass == 0);
+      const unsigned long long m = __ballot(own);
+      if (own) {
+        ent[n_ent + __popcll(m & ((1ull << lane) - 1))] =
+            (uint32_t)(bx.hi & 255) | ((uint32_t)(bx.lo & 255) << 8) | ((uint32_t)i << 16);
+        max_dxw = max(max_dxw, (uint32_t)(bx.hi - bx.lo));
+      }
+      n_ent += __popcll(m);
     }
-    n_ent += __popcll(m);
-  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) max_dxw = max(max_dxw, (uint32_t)__shfl_xor((int)max_dxw, off, 64));
   max_dxw = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_dxw);
