@@ -10,6 +10,7 @@ O=$R/gpurun_out
 mkdir -p $O
 python $R/bench.py > $O/${tag}_bench_default.json || exit 1
 echo "default done"
+python $R/bench.py --one-pass off --no-cpu-baseline --no-variants > $O/${tag}_bench_two_calls.json || exit 1
 python $R/bench.py --frames-per-call 1 --no-cpu-baseline --no-variants > $O/${tag}_bench_per_frame_calls.json || exit 1
 python $R/bench.py --frames-per-call 8 --no-cpu-baseline --no-variants > $O/${tag}_bench_8_frames_per_call_three_kernels.json || exit 1
 python $R/bench.py --frames-per-call 32 --no-cpu-baseline --no-variants > $O/${tag}_bench_32_frames_per_call.json || exit 1
@@ -36,6 +37,6 @@ rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_
 echo "pmc groups 1-2 done"
 cd $R && $R/scripts/pmc_traffic_only.sh ${tag} || exit 1
 echo "pmc traffic done"
-python $R/scripts/pmc_summary.py $O/pmc_${tag}_1 $O/pmc_${tag}_2 $O/pmc_${tag}_d4 $O/pmc_${tag}_d5 > $O/${tag}_pmc_summary.txt
+python $R/scripts/pmc_summary.py $O/pmc_${tag}_1 $O/pmc_${tag}_2 $O/pmc_${tag}_d4 $O/pmc_${tag}_d5 $O/pmc_${tag}_t4 $O/pmc_${tag}_t5 > $O/${tag}_pmc_summary.txt
 python $R/scripts/pmc_summary.py $O/pmc_${tag}_yuv_d4 $O/pmc_${tag}_yuv_d5 > $O/${tag}_yuv_pmc_summary.txt
 echo "all done"

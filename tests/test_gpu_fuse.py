@@ -253,3 +253,16 @@ def test_one_pass_refuses_to_allocate_under_stream_capture(f360, gpu_ctx):
         assert torch.equal(reds, want)
     dec.close()
     ctx.close()
+
+
+def test_config4_batch_through_the_one_pass_call(f360, oracle):
+    """BASELINE config 4 the way bench.py runs it by default: 32 of its frames (31 LCG frames + the
+    all-255 frame whose sums wrap mod 2^32) resident, ONE EncodeSampleFramesGPU call; every table
+    and every reduced frame equals the ORACLE's by digest."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_configs
+    res = bench_configs.config4_batched(f360, oracle, quick=True, one_pass=True)
+    assert "EncodeSampleFramesGPU" in res["workload"] and "sat_walk_kernel" in res["workload"], res
+    assert res["bad_frames"] == [], res
