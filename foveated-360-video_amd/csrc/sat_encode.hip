@@ -1016,7 +1016,9 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
                                                uint32_t max_dxw, const int (&xcol)[3],
                                                const int (&xslot)[3], int npix, uint32_t *side,
                                                int unit) {
-  const bool exports = __any(xslot[0] >= 0 || xslot[1] >= 0 || xslot[2] >= 0);
+  const bool exports_k[3] = {(bool)__any(xslot[0] >= 0), (bool)__any(xslot[1] >= 0),
+                             (bool)__any(xslot[2] >= 0)};
+  const bool exports = exports_k[0] || exports_k[1] || exports_k[2];
   // this lane's pixel of round k: D-row byte offsets of its two columns, box width, target
   uint32_t eoff[NR], estore[NR];
   float einv[NR];
@@ -1052,7 +1054,17 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
       const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)pv, r);
       if (!(pr & kFuseEmit)) continue;
       const unsigned long long c0 = timed ? __builtin_amdgcn_s_memtime() : 0;
-      while (lds_read_b32(mbox + r * 4) != pr) __builtin_amdgcn_s_sleep(1);
+      // (two quick looks, then long naps: a helper of a sparse strip waits most of the time,
+      // and every look costs its SIMD -- its owner's SIMD -- issue slots and an LDS access)
+#ifndef F360_FUSE_NAP
+#define F360_FUSE_NAP 8
+#endif
+      for (int looks = 0; lds_read_b32(mbox + r * 4) != pr; ++looks) {
+        if (looks < 2)
+          __builtin_amdgcn_s_sleep(1);
+        else
+          __builtin_amdgcn_s_sleep(F360_FUSE_NAP);
+      }
       const unsigned long long c1 = timed ? __builtin_amdgcn_s_memtime() : 0;
       const uint32_t dy = (pr >> 16) & 0x3ffu;
       uint8_t *orow = dst + (size_t)(pr & 0xffffu) * wf.dst_linesize;
@@ -1078,7 +1090,7 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
       if (exports) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)  // (every lane reads -- column 0 if it has nothing to export)
-          fuse_lds_read3(dlds + (uint32_t)xcol[k] * 12u, x01[k], x2[k]);
+          if (exports_k[k]) fuse_lds_read3(dlds + (uint32_t)xcol[k] * 12u, x01[k], x2[k]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
