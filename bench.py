@@ -236,7 +236,14 @@ def main():
             "frames_total": sum(len(r) for r in plan),
             "ranks": [{"rank": r, "frames": [rg.start, rg.stop],
                        "frames_per_call": min(args.frames_per_call, len(rg)),
-                       "encoder": encoder_plan(args.width, min(args.frames_per_call, len(rg)), args.opt)}
+                       "encoder": encoder_plan(args.width, min(args.frames_per_call, len(rg)), args.opt),
+                       # tables and reduced frames from one pass of the read-once encoder: only
+                       # where that encoder runs, from RGB0 (else the library makes the two calls)
+                       "one_pass": (args.one_pass == "on" and args.source == "rgb0" and not args.fused
+                                    and min(args.frames_per_call, len(rg)) > 1
+                                    and encoder_plan(args.width, min(args.frames_per_call, len(rg)),
+                                                     args.opt).startswith("read-once")
+                                    and dict(kv.split("=") for kv in args.opt).get("fuse.walk", "1") != "0")}
                       for r, rg in enumerate(plan)],
             "launch": (self_launch(args, argv) if args.gpus > 1 and not launched
                        else [sys.executable, os.path.abspath(__file__)] + argv)}))
