@@ -1056,14 +1056,11 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
       const unsigned long long c0 = timed ? __builtin_amdgcn_s_memtime() : 0;
       // (two quick looks, then long naps: a helper of a sparse strip waits most of the time,
       // and every look costs its SIMD -- its owner's SIMD -- issue slots and an LDS access)
-#ifndef F360_FUSE_NAP
-#define F360_FUSE_NAP 8
-#endif
       for (int looks = 0; lds_read_b32(mbox + r * 4) != pr; ++looks) {
         if (looks < 2)
           __builtin_amdgcn_s_sleep(1);
         else
-          __builtin_amdgcn_s_sleep(F360_FUSE_NAP);
+          __builtin_amdgcn_s_sleep(8);
       }
       const unsigned long long c1 = timed ? __builtin_amdgcn_s_memtime() : 0;
       const uint32_t dy = (pr >> 16) & 0x3ffu;
@@ -1098,7 +1095,7 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
         asm volatile("" : "+v"(h01[k]), "+v"(h2[k]), "+v"(l01[k]), "+v"(l2[k]));
 #pragma unroll
       for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(x01[k]), "+v"(x2[k]));
-      if (!(a.ablate & 512)) {
+      {
         uint3 n[NR];
 #pragma unroll
         for (int k = 0; k < NR; ++k)
@@ -1138,7 +1135,7 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
           fuse_store_rgb(orow, (en >> 16) * 4, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
         }
       }
-      if (exports && !(a.ablate & 8192)) {  // this strip's columns of the boxes that straddle two strips
+      if (exports) {  // this strip's columns of the boxes that straddle two strips
         uint32_t *srow = side + (size_t)(pr & 0xffffu) * npix * 6;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -1346,6 +1343,13 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
 #pragma unroll
       for (int r = 0; r < kRowUnroll; ++r) {
         if (y + r > y_last) break;
+        // encode + sample: a first look at this row's D-row slot, issued now and read after the
+        // staging round trip below has waited for it anyway
+        uint32_t slot_word = 0;
+        if constexpr (FUSE) {
+          if (pw[r] & kFuseEmit)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(slot_word) : "v"(mbox + r * 4) : "memory");
+        }
         uint32_t c[12], px[4];
         batch_pixels<SRC>(a, raw, r, px);
         unpack_px4(make_uint4(px[0], px[1], px[2], px[3]), c);
@@ -1389,9 +1393,11 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
             // D = this row - snapshot into slot r, once the helper is done with the slot's
             // previous row (a batch ago), then the plan word into the mailbox: the payload is
             // in LDS before its flag (one wave's LDS operations execute in order)
-            while (lds_read_b32(mbox + r * 4) != 0) {
+            asm volatile("" : "+v"(slot_word));  // (returned before lds_read3_b128's wait)
+            while (slot_word != 0) {
               ++box_spins;
               __builtin_amdgcn_s_sleep(1);
+              slot_word = lds_read_b32(mbox + r * 4);
             }
             const uint32_t da = dbase + (uint32_t)r * (3 * kStripPx * 4) + lane * 48;
             lds_write_b128(da, u32x4{acc[0] - snap[0], acc[1] - snap[1], acc[2] - snap[2],
@@ -1403,8 +1409,8 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
             if (one_row)
               lds_write_b128(dbase + (uint32_t)(kRowUnroll * 3 + r) * (kStripPx * 4) + lane * 16,
                              u32x4{px[0], px[1], px[2], px[3]});
-            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(mbox + r * 4), "v"(pr)
-                         : "memory");
+            // (no wait between payload and flag: LDS executes one wave's operations in order)
+            asm volatile("ds_write_b32 %0, %1" ::"v"(mbox + r * 4), "v"(pr) : "memory");
           }
           if (pr & kFuseSnap) {
 #pragma unroll

@@ -1,6 +1,8 @@
 """Where the one-pass encode + sample spends its time, per strip position: one launch of 23 8K
 frames with debug.ablate bit 8 (per-unit clocks and wait counts of the strip owners).
-    python scripts/fuse_stats.py [frames]"""
+    python scripts/fuse_stats.py [frames]
+(the helper's timed sections cost a few hundred cycles per row themselves: compare strips, do not
+read the cycle counts as absolute)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +11,6 @@ import torch
 import f360_amd as f360
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 23
-extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 w, h = 7680, 3840
 rw, rh = f360.reduced_size(w), f360.reduced_size(h)
 dev = torch.device("cuda", 0)
@@ -29,7 +30,7 @@ for mode in (1, 0):
     ctx.set_option("fuse.walk", mode)
     ctx.set_option("debug.ablate", 0)
     dec.EncodeSampleFramesGPU(*args)
-    ctx.set_option("debug.ablate", 256 | (extra if mode else 0))
+    ctx.set_option("debug.ablate", 256)
     if mode == 0:
         f360.SATEncoder(ctx).EncodeFramesGPU(args[4], args[5], w, h, 4 * w)
     else:
