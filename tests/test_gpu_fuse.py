@@ -266,3 +266,54 @@ def test_config4_batch_through_the_one_pass_call(f360, oracle):
     res = bench_configs.config4_batched(f360, oracle, quick=True, one_pass=True)
     assert "EncodeSampleFramesGPU" in res["workload"] and "sat_walk_kernel" in res["workload"], res
     assert res["bad_frames"] == [], res
+
+
+def test_two_one_pass_launches_share_the_device(f360, oracle):
+    """Two contexts (two streams, two threads) run one-pass launches at the same time.  A workgroup
+    of the one-pass kernel takes a CU's LDS for itself, so the two launches compete for CUs; a strip
+    owner only ever waits for a unit whose workgroup already runs and a helper only for its own
+    owner, so both launches drain and both are right -- tables and reduced frames."""
+    import threading
+    w, h, n = 2304, 200, 40   # 9 strips x 40 frames = 360 units = 90 workgroups per launch
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    results = {}
+
+    def worker(tag, seed):
+        rng = np.random.default_rng(seed)
+        with f360.Context(0) as ctx:
+            ctx.set_option("sat.walk", 1)
+            dec = f360.SATDecoder(ctx)
+            dec.InitializeGrid(rw, rh, w, h)
+            frames = [oracle.lcg_frame(w, h, seed + k) for k in range(n)]
+            gazes = [(float(rng.uniform(-0.1, 1.1)), float(rng.uniform(-0.1, 1.1))) for _ in range(n)]
+            srcs = [ctx.upload(f) for f in frames]
+            sats = [ctx.malloc(w * h * 12) for _ in range(n)]
+            reds = [ctx.malloc(rw * rh * 4) for _ in range(n)]
+            bad = []
+            for rep in range(4):
+                for b in sats:
+                    b.fill(rep + 1)
+                for b in reds:
+                    b.fill(0x40 + rep)
+                dec.EncodeSampleFramesGPU([b.ptr for b in reds], rw, rh, 4 * rw, [b.ptr for b in sats],
+                                          [b.ptr for b in srcs], w, h, 4 * w, gazes)
+                ctx.finish()
+                for k in (0, n // 2, n - 1):
+                    want_sat = oracle.sat_encode(frames[k], w, h, 4 * w)
+                    want = np.full((rh, 4 * rw), 0x40 + rep, dtype=np.uint8)
+                    oracle.satdec_sample_rect(want, rw, rh, 4 * rw, want_sat, w, h, grid, *gazes[k])
+                    if not (np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want_sat) and
+                            np.array_equal(reds[k].copy_to_host(np.uint8, (rh, 4 * rw)), want)):
+                        bad.append((rep, k))
+            for b in srcs + sats + reds:
+                b.free()
+            dec.close()
+            results[tag] = (bad, ctx.debug_walk_recoveries())
+
+    threads = [threading.Thread(target=worker, args=(t, 700 + 100 * t)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert results == {0: ([], 0), 1: ([], 0)}, results
