@@ -1,7 +1,8 @@
 """Soak of the one-pass encode + sample (f360_satdec_encode_sample_frames with the read-once
 encoder forced on) against the two calls it replaces, byte for byte, on random geometries, frame
 counts, gaze points (inside, on and beyond every edge), padded targets:
-    python scripts/fuse_soak.py [seconds] [seed]"""
+    python scripts/fuse_soak.py [seconds] [seed] [big]
+("big": frames of 2560x1280 to 7680x3840, up to 5 per call -- dozens of strips, thousands of rows)"""
 import os
 import sys
 import time
@@ -11,6 +12,7 @@ import f360_amd as f360
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 t0 = time.time()
 calls = frames_done = bad = 0
@@ -19,8 +21,11 @@ with f360.Context(0) as ctx:
     ctx.set_option("sat.walk", 1)
     enc = f360.SATEncoder(ctx)
     while time.time() - t0 < budget:
-        kind = rng.integers(0, 4)
-        if kind == 0:
+        kind = rng.integers(0, 4) if not big else 9
+        if big:
+            w = 256 * int(rng.integers(10, 31)) - 4 * int(rng.integers(0, 3))
+            h = 8 * int(rng.integers(100, 481)) - int(rng.integers(0, 8))
+        elif kind == 0:
             w, h = 4 * int(rng.integers(1, 300)), int(rng.integers(2, 200))
         elif kind == 1:
             w, h = 4 * int(rng.integers(200, 1100)), int(rng.integers(2, 120))
@@ -28,7 +33,7 @@ with f360.Context(0) as ctx:
             w, h = 4 * int(rng.integers(16, 200)), int(rng.integers(100, 1200))
         else:
             w, h = 256 * int(rng.integers(1, 12)), 8 * int(rng.integers(1, 60))
-        n = int(rng.integers(1, 14))
+        n = int(rng.integers(1, 14)) if not big else int(rng.integers(1, 6))
         rw, rh = f360.reduced_size(w), f360.reduced_size(h)
         tpad = 4 * int(rng.integers(0, 5))
         tl = 4 * rw + tpad
