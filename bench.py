@@ -238,8 +238,8 @@ def main():
                        "frames_per_call": min(args.frames_per_call, len(rg)),
                        "encoder": encoder_plan(args.width, min(args.frames_per_call, len(rg)), args.opt),
                        # tables and reduced frames from one pass of the read-once encoder: only
-                       # where that encoder runs, from RGB0 (else the library makes the two calls)
-                       "one_pass": (args.one_pass == "on" and args.source == "rgb0" and not args.fused
+                       # where that encoder runs (else the library makes the two calls)
+                       "one_pass": (args.one_pass == "on" and not args.fused
                                     and min(args.frames_per_call, len(rg)) > 1
                                     and encoder_plan(args.width, min(args.frames_per_call, len(rg)),
                                                      args.opt).startswith("read-once")
@@ -330,7 +330,7 @@ def main():
         return keep, keep
 
     placement = {"policy": args.placement, "tried": []}
-    walks = (not args.fused and not yuv and args.placement == "auto" and
+    walks = (not args.fused and args.placement == "auto" and
              encoder_plan(w, fpc, args.opt).startswith("read-once"))
     if not walks:
         how = "separate" if args.placement == "auto" else args.placement
@@ -363,7 +363,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     calls = [0]
-    one_pass = args.one_pass == "on" and not yuv and not args.fused and fpc > 1
+    one_pass = args.one_pass == "on" and not args.fused and fpc > 1
 
     def step_batched(profile):
         # frames [g, g + n) in one encode call and one sample call; --profile-every counts
@@ -381,7 +381,11 @@ def main():
                         streams[s].wait_stream(streams[o])
                 ctxs[s].profile_arm(1 if one_pass else 2)
             mine_sats = sat_ptr[s * fpc:s * fpc + n]
-            if one_pass:
+            if one_pass and yuv:
+                decs[s].EncodeSampleFramesYUV420PGPU(red_ptr[g:g + n], rw, rh, 4 * rw, mine_sats,
+                                                     yuv_ptr[g:g + n], w, w // 2, w // 2, w, h,
+                                                     gazes[g:g + n])
+            elif one_pass:
                 decs[s].EncodeSampleFramesGPU(red_ptr[g:g + n], rw, rh, 4 * rw, mine_sats,
                                               frame_ptr[g:g + n], w, h, 4 * w, gazes[g:g + n])
             elif yuv:
@@ -519,7 +523,7 @@ def main():
                     pmc = doc
             except Exception:
                 pmc = {}
-        size_key = f"{w}x{h}" + (":yuv420p" if yuv else ":one_pass" if one_pass_ran else "")
+        size_key = f"{w}x{h}" + (":yuv420p" if yuv else "") + (":one_pass" if one_pass_ran else "")
 
         def roof_of(name):
             k = kernels[name]
@@ -569,9 +573,12 @@ def main():
                                       if fpc > 1 else "")
                                    + ", Lissajous gaze, inputs resident in HBM",
                        "source": args.source, "fused": bool(args.fused),
-                       "call": ("EncodeSampleFramesGPU" if one_pass else "FoveateFrameRectGPU"
-                                if args.fused else "EncodeFramesGPU + SampleFramesRectGPU"
-                                if fpc > 1 else "EncodeFrameGPU + SampleFrameRectGPU"),
+                       "call": ("EncodeSampleFramesYUV420PGPU" if one_pass and yuv
+                                else "EncodeSampleFramesGPU" if one_pass else "FoveateFrameRectGPU"
+                                if args.fused
+                                else ("EncodeFramesYUV420PGPU" if yuv else "EncodeFramesGPU") + " + SampleFramesRectGPU"
+                                if fpc > 1
+                                else ("EncodeFrameYUV420PGPU" if yuv else "EncodeFrameGPU") + " + SampleFrameRectGPU"),
                        "frame": [w, h], "reduced": [rw, rh], "batch_per_gpu": B,
                        "global_batch": args.global_batch or None,
                        "streams_per_gpu": nstreams, "frames_per_call": fpc,
@@ -626,7 +633,11 @@ def main():
             def two_calls():
                 for g in range(0, B, fpc):
                     n = min(fpc, B - g)
-                    encs[0].EncodeFramesGPU(sat_ptr[:n], frame_ptr[g:g + n], w, h, 4 * w)
+                    if yuv:
+                        encs[0].EncodeFramesYUV420PGPU(sat_ptr[:n], yuv_ptr[g:g + n], w, w // 2,
+                                                       w // 2, w, h)
+                    else:
+                        encs[0].EncodeFramesGPU(sat_ptr[:n], frame_ptr[g:g + n], w, h, 4 * w)
                     decs[0].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n], (w, h),
                                                 gazes[g:g + n])
             two_calls()
@@ -637,7 +648,8 @@ def main():
             torch.cuda.synchronize(dev)
             two_value = 5 * B * w * h / 1e6 / (time.perf_counter() - t1)
             line["value_two_calls"] = round(two_value, 1)
-            line["two_calls"] = ("EncodeFramesGPU + SampleFramesRectGPU on the same frames, 5 steps "
+            line["two_calls"] = (("EncodeFramesYUV420PGPU" if yuv else "EncodeFramesGPU") +
+                                 " + SampleFramesRectGPU on the same frames, 5 steps "
                                  "after the timed region; path_hbm_frac "
                                  f"{path_bytes * two_value * 1e6 / (w * h) / 1e9 / HBM_PEAK_GBS:.4f}")
         if world == 1 and not args.no_variants and not args.fused and not yuv:

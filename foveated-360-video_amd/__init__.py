@@ -116,6 +116,11 @@ _SIGNATURES = {
     "f360_satdec_encode_sample_frames": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                                  POINTER(c_void_p), c_int, c_int, c_int, c_int,
                                                  c_int, c_int, c_int, POINTER(c_float)]),
+    "f360_satdec_encode_sample_frames_yuv420p": (c_int, [c_void_p, POINTER(c_void_p),
+                                                         POINTER(c_void_p), POINTER(c_void_p),
+                                                         POINTER(c_void_p), POINTER(c_void_p),
+                                                         c_int, c_int, c_int, c_int, c_int, c_int,
+                                                         c_int, c_int, c_int, POINTER(c_float)]),
     "f360_satdec_foveate_rect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                          c_int, c_int, c_float, c_float]),
     "f360_satdec_foveate_rect_yuv420p": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int,
@@ -584,6 +589,25 @@ class SATDecoder:
                                                       target_height, target_linesize,
                                                       source_width, source_height,
                                                       source_linesize, xy))
+
+    def EncodeSampleFramesYUV420PGPU(self, cl_target_buffers, target_width, target_height,
+                                     target_linesize, cl_tables, planes, y_linesize, u_linesize,
+                                     v_linesize, source_width, source_height, centers) -> None:
+        """EncodeSampleFramesGPU from planar YUV 4:2:0 frames: `planes` is a list of (y, u, v)
+        device pointers (f360_satdec_encode_sample_frames_yuv420p)."""
+        self._need("EncodeSampleFramesYUV420PGPU")
+        n = len(cl_target_buffers)
+        if n != len(cl_tables) or n != len(planes) or n != len(centers):
+            raise ValueError("EncodeSampleFramesYUV420PGPU: as many targets as tables, frames and gaze points")
+        dsts = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        sats = (c_void_p * n)(*[int(p) for p in cl_tables])
+        ys = (c_void_p * n)(*[int(p[0]) for p in planes])
+        us = (c_void_p * n)(*[int(p[1]) for p in planes])
+        vs = (c_void_p * n)(*[int(p[2]) for p in planes])
+        xy = (c_float * (2 * n))(*[float(v) for c in centers for v in c])
+        _check(lib().f360_satdec_encode_sample_frames_yuv420p(
+            self._h, dsts, sats, ys, us, vs, y_linesize, u_linesize, v_linesize, n, target_width,
+            target_height, target_linesize, source_width, source_height, xy))
 
     def FoveateFrameRectGPU(self, cl_target_buffer, target_width, target_height,
                             target_linesize, cl_source_frame, source_width, source_height,

@@ -281,11 +281,14 @@ struct SatFuse {
   const int16_t *gx, *gy;
   int out_w, out_h, dst_linesize;
 };
+// `yuv` / `yuvs` non-null: planar sources (srcs / linesize unused; every frame's planes with
+// yuvs[0]'s linesizes)
 bool sat_encode_sample_applies(const f360_ctx *ctx, int count, int width, int height,
-                               int linesize, int out_w, int out_h, int dst_linesize);
+                               int linesize, int out_w, int out_h, int dst_linesize,
+                               const YuvPlanes *yuv = nullptr);
 int sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats,
-                           const uint8_t *const *srcs, int width, int height, int linesize,
-                           const SatFuse &fuse, bool prof);
+                           const uint8_t *const *srcs, const YuvPlanes *yuvs, int width,
+                           int height, int linesize, const SatFuse &fuse, bool prof);
 }  // namespace f360
 
 struct f360_event {

@@ -1277,17 +1277,20 @@ int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *target
 // Encode + sample in one pass over the frames: tables AND reduced frames, byte for byte what
 // f360_sat_encode_batch followed by f360_satdec_sample_rect_frames leave (which is what this
 // call does whenever the one-pass form does not apply: too few frames for the read-once encoder,
-// a source that is not 16-byte aligned RGB0, a grid whose offsets do not increase strictly).
-int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+// a source the read-once encoder does not take, a grid whose offsets do not increase strictly).
+// `planes` non-null: planar YUV 4:2:0 sources (sources_dev / source_linesize unused).
+static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targets_dev,
                                      uint32_t *const *sats_dev, const uint8_t *const *sources_dev,
-                                     int count, int target_width, int target_height,
-                                     int target_linesize, int source_width, int source_height,
-                                     int source_linesize, const float *centers_xy) {
-  F360_REQUIRE(dec && targets_dev && sats_dev && sources_dev && centers_xy && count >= 1,
+                                     const f360::YuvPlanes *planes, int count, int target_width,
+                                     int target_height, int target_linesize, int source_width,
+                                     int source_height, int source_linesize,
+                                     const float *centers_xy) {
+  F360_REQUIRE(dec && targets_dev && sats_dev && (sources_dev || planes) && centers_xy &&
+                   count >= 1,
                "f360_satdec_encode_sample_frames: bad arguments");
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width &&
-                   source_linesize >= 1,
+                   (planes || source_linesize >= 1),
                "f360_satdec_encode_sample_frames: bad geometry");
   F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}),
                "f360_satdec_encode_sample_frames: a dimension exceeds 65536");
@@ -1295,12 +1298,18 @@ int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targ
   bool one_pass = ctx->opt_fuse_walk != 0 &&
                   f360::sat_encode_sample_applies(ctx, count, source_width, source_height,
                                                   source_linesize, target_width, target_height,
-                                                  target_linesize);
-  for (int k = 0; k < count && one_pass; ++k)
-    one_pass = targets_dev[k] && sats_dev[k] && sources_dev[k] &&
-               ((uintptr_t)sources_dev[k] % 16) == 0 && ((uintptr_t)sats_dev[k] % 16) == 0 &&
+                                                  target_linesize, planes);
+  for (int k = 0; k < count && one_pass; ++k) {
+    one_pass = targets_dev[k] && sats_dev[k] && ((uintptr_t)sats_dev[k] % 16) == 0 &&
                ((uintptr_t)targets_dev[k] % 4) == 0 && std::fabs(centers_xy[2 * k]) <= 16.0f &&
                std::fabs(centers_xy[2 * k + 1]) <= 16.0f;
+    if (planes)
+      one_pass = one_pass && planes[k].y && planes[k].u && planes[k].v &&
+                 ((uintptr_t)planes[k].y % 4) == 0 && ((uintptr_t)planes[k].u % 2) == 0 &&
+                 ((uintptr_t)planes[k].v % 2) == 0;
+    else
+      one_pass = one_pass && sources_dev[k] && ((uintptr_t)sources_dev[k] % 16) == 0;
+  }
   if (one_pass) {
     F360_BIND_DEVICE(ctx);
     if (!dec->gx_dev.p) {
@@ -1324,16 +1333,56 @@ int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targ
     const f360::SatFuse fuse{targets_dev, centers_xy, dec->gx_dev.as<int16_t>(),
                              dec->gy_dev.as<int16_t>(), target_width, target_height,
                              target_linesize};
-    return f360::sat_encode_sample_walk(ctx, count, sats_dev, sources_dev, source_width,
+    return f360::sat_encode_sample_walk(ctx, count, sats_dev, sources_dev, planes, source_width,
                                         source_height, source_linesize, fuse,
                                         f360::take_profile_slot(ctx));
   }
-  int st = f360_sat_encode_batch(ctx, count, sats_dev, sources_dev, source_width, source_height,
-                                 source_linesize);
+  int st;
+  if (planes) {
+    std::vector<const uint8_t *> y((size_t)count), u((size_t)count), v((size_t)count);
+    for (int k = 0; k < count; ++k) {
+      y[(size_t)k] = planes[k].y;
+      u[(size_t)k] = planes[k].u;
+      v[(size_t)k] = planes[k].v;
+    }
+    st = f360_sat_encode_yuv420p_batch(ctx, count, sats_dev, y.data(), u.data(), v.data(),
+                                       planes[0].y_linesize, planes[0].u_linesize,
+                                       planes[0].v_linesize, source_width, source_height);
+  } else {
+    st = f360_sat_encode_batch(ctx, count, sats_dev, sources_dev, source_width, source_height,
+                               source_linesize);
+  }
   if (st != F360_OK) return st;
   return f360_satdec_sample_rect_frames(dec, targets_dev, count, target_width, target_height,
                                         target_linesize, sats_dev, source_width, source_height,
                                         centers_xy);
+}
+
+int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                     uint32_t *const *sats_dev, const uint8_t *const *sources_dev,
+                                     int count, int target_width, int target_height,
+                                     int target_linesize, int source_width, int source_height,
+                                     int source_linesize, const float *centers_xy) {
+  return encode_sample_frames_impl(dec, targets_dev, sats_dev, sources_dev, nullptr, count,
+                                   target_width, target_height, target_linesize, source_width,
+                                   source_height, source_linesize, centers_xy);
+}
+
+int f360_satdec_encode_sample_frames_yuv420p(
+    f360_sat_decoder *dec, uint8_t *const *targets_dev, uint32_t *const *sats_dev,
+    const uint8_t *const *y_dev, const uint8_t *const *u_dev, const uint8_t *const *v_dev,
+    int y_linesize, int u_linesize, int v_linesize, int count, int target_width,
+    int target_height, int target_linesize, int source_width, int source_height,
+    const float *centers_xy) {
+  F360_REQUIRE(y_dev && u_dev && v_dev && count >= 1,
+               "f360_satdec_encode_sample_frames_yuv420p: bad arguments");
+  std::vector<f360::YuvPlanes> planes((size_t)count);
+  for (int k = 0; k < count; ++k)
+    planes[(size_t)k] =
+        f360::YuvPlanes{y_dev[k], u_dev[k], v_dev[k], y_linesize, u_linesize, v_linesize};
+  return encode_sample_frames_impl(dec, targets_dev, sats_dev, nullptr, planes.data(), count,
+                                   target_width, target_height, target_linesize, source_width,
+                                   source_height, 0, centers_xy);
 }
 
 }  // extern "C"

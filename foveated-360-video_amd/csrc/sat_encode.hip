@@ -1008,7 +1008,7 @@ __device__ __forceinline__ uint3 fuse_div3(uint3 n, uint32_t d) {
 // 1/2048 below the next integer (tests/test_fuse_div.py walks every case); larger boxes divide.
 constexpr int kFuseRounds = 5;
 
-template <int NR>
+template <int NR, bool PIX>
 __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFuse &wf,
                                                const uint32_t *plan, uint8_t *dst, int lane,
                                                const uint32_t *ent, int n_ent,
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
           drows + kRowUnroll * 3 * kStripPx + r * kStripPx);  // the source pixels of the row
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
-        if (one_row && unit_wide[k]) {  // the fovea: a reduced pixel IS a source pixel
+        if (PIX && one_row && unit_wide[k]) {  // the fovea: a reduced pixel IS a source pixel
           asm volatile("ds_read_b32 %0, %1" : "=v"(h2[k]) : "v"(plds + (estore[k] >> 22) * 4u) : "memory");
         } else {
           fuse_lds_read3(dlds + (eoff[k] & 0xfffu), h01[k], h2[k]);
@@ -1104,13 +1104,17 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
           const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
-            if (one_row && unit_wide[k]) {  // R, G from the low half, B from byte 2
-              if (valid[k])
-                asm volatile(
-                    "global_store_short %0, %1, %2 nt\n\t"
-                    "global_store_byte_d16_hi %0, %1, %2 offset:2 nt" ::"v"(estore[k] & 0x3fffffu),
-                    "v"(h2[k]), "s"(orow)
-                    : "memory");
+            if (one_row && unit_wide[k]) {
+              if (PIX) {  // the posted source pixel: R, G from the low half, B from byte 2
+                if (valid[k])
+                  asm volatile(
+                      "global_store_short %0, %1, %2 nt\n\t"
+                      "global_store_byte_d16_hi %0, %1, %2 offset:2 nt" ::"v"(estore[k] & 0x3fffffu),
+                      "v"(h2[k]), "s"(orow)
+                      : "memory");
+              } else if (valid[k]) {  // (planar sources post no pixel rows) a box of one: n itself
+                fuse_store_rgb(orow, estore[k] & 0x3fffffu, n[k].x | (n[k].y << 8), n[k].z);
+              }
               continue;
             }
             const float inv = einv[k] * inv_dy;
@@ -1161,6 +1165,7 @@ __device__ __forceinline__ void walk_fuse_rows(const EncodeArgs &a, const WalkFu
   }
 }
 
+template <bool PIX>
 __device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const WalkFuse &wf,
                                                  int unit, int lane, uint32_t *ent,
                                                  uint32_t *box) {
@@ -1215,7 +1220,7 @@ __device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const Walk
   }
   uint32_t *side = wf.side + (size_t)f * wf.side_stride;
 #define F360_FUSE_ROWS(NR)                                                                  \
-  walk_fuse_rows<NR>(a, wf, plan, dst, lane, ent, n_ent, drows, mbox, max_dxw, xcol, xslot, \
+  walk_fuse_rows<NR, PIX>(a, wf, plan, dst, lane, ent, n_ent, drows, mbox, max_dxw, xcol, xslot, \
                      npix, side, unit)
   if (n_ent <= 64) F360_FUSE_ROWS(1);
   else if (n_ent <= 128) F360_FUSE_ROWS(2);
@@ -1253,7 +1258,7 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
   if constexpr (FUSE) {
     if (helper) {
       if (unit < a.walk_units)
-        walk_fuse_helper(a, wf, unit, lane, fuse_lds + wave * kFuseWaveDwords,
+        walk_fuse_helper<SRC == kSrcRgb0>(a, wf, unit, lane, fuse_lds + wave * kFuseWaveDwords,
                          fuse_box + wave * kRowUnroll);
       return;
     }
@@ -1290,15 +1295,26 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
     for (int e = 0; e < 12; ++e) acc[e] = 0;
     uint32_t slow_polls = 0, spun = 0;  // hand-off waits that took the slow path, their polls
     // encode + sample: the table row at the last snapshot; D rows and their mailbox (LDS)
-    uint32_t snap[12];
+    // (planar sources convert in registers and have none to spare: their snapshot lives in LDS,
+    // in place of the source-pixel rows, which they do not post)
+    constexpr bool kPix = FUSE && SRC == kSrcRgb0;
+    constexpr bool kLdsSnap = FUSE && SRC != kSrcRgb0;
+    uint32_t snap[kLdsSnap ? 1 : 12];
     uint32_t box_spins = 0;  // polls spent waiting for the helper to hand a D-row slot back
     const uint32_t dbase =
         (uint32_t)reinterpret_cast<uintptr_t>(fuse_lds + wave * kFuseWaveDwords + kFuseEntries);
     const uint32_t mbox = (uint32_t)reinterpret_cast<uintptr_t>(fuse_box + wave * kRowUnroll);
     const uint32_t *plan = nullptr;
     if constexpr (FUSE) {
+      if constexpr (kLdsSnap) {
+        const uint32_t sa = dbase + (uint32_t)(kRowUnroll * 3) * (kStripPx * 4) + lane * 48;
+        lds_write_b128(sa, u32x4{0, 0, 0, 0});
+        lds_write_b128(sa + 16, u32x4{0, 0, 0, 0});
+        lds_write_b128(sa + 32, u32x4{0, 0, 0, 0});
+      } else {
 #pragma unroll
-      for (int e = 0; e < 12; ++e) snap[e] = 0;
+        for (int e = 0; e < 12; ++e) snap[e] = 0;
+      }
       plan = wf.rowplan + (size_t)f * wf.plan_stride;
     }
     const unsigned long long t_start = (a.ablate & 256) ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -1400,21 +1416,47 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
               slot_word = lds_read_b32(mbox + r * 4);
             }
             const uint32_t da = dbase + (uint32_t)r * (3 * kStripPx * 4) + lane * 48;
-            lds_write_b128(da, u32x4{acc[0] - snap[0], acc[1] - snap[1], acc[2] - snap[2],
-                                     acc[3] - snap[3]});
-            lds_write_b128(da + 16, u32x4{acc[4] - snap[4], acc[5] - snap[5], acc[6] - snap[6],
-                                          acc[7] - snap[7]});
-            lds_write_b128(da + 32, u32x4{acc[8] - snap[8], acc[9] - snap[9],
-                                          acc[10] - snap[10], acc[11] - snap[11]});
-            if (one_row)
-              lds_write_b128(dbase + (uint32_t)(kRowUnroll * 3 + r) * (kStripPx * 4) + lane * 16,
-                             u32x4{px[0], px[1], px[2], px[3]});
+            uint32_t sv[12];
+            if constexpr (kLdsSnap) {
+              u32x4 s0, s1, s2;
+              asm volatile(
+                  "ds_read_b128 %0, %3\n\t"
+                  "ds_read_b128 %1, %3 offset:16\n\t"
+                  "ds_read_b128 %2, %3 offset:32\n\t"
+                  "s_waitcnt lgkmcnt(0)"
+                  : "=&v"(s0), "=&v"(s1), "=&v"(s2)
+                  : "v"(dbase + (uint32_t)(kRowUnroll * 3) * (kStripPx * 4) + lane * 48)
+                  : "memory");
+              sv[0] = s0.x, sv[1] = s0.y, sv[2] = s0.z, sv[3] = s0.w;
+              sv[4] = s1.x, sv[5] = s1.y, sv[6] = s1.z, sv[7] = s1.w;
+              sv[8] = s2.x, sv[9] = s2.y, sv[10] = s2.z, sv[11] = s2.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 12; ++e) sv[e] = snap[e];
+            }
+            lds_write_b128(da, u32x4{acc[0] - sv[0], acc[1] - sv[1], acc[2] - sv[2],
+                                     acc[3] - sv[3]});
+            lds_write_b128(da + 16, u32x4{acc[4] - sv[4], acc[5] - sv[5], acc[6] - sv[6],
+                                          acc[7] - sv[7]});
+            lds_write_b128(da + 32, u32x4{acc[8] - sv[8], acc[9] - sv[9],
+                                          acc[10] - sv[10], acc[11] - sv[11]});
+            if constexpr (kPix)
+              if (one_row)
+                lds_write_b128(dbase + (uint32_t)(kRowUnroll * 3 + r) * (kStripPx * 4) + lane * 16,
+                               u32x4{px[0], px[1], px[2], px[3]});
             // (no wait between payload and flag: LDS executes one wave's operations in order)
             asm volatile("ds_write_b32 %0, %1" ::"v"(mbox + r * 4), "v"(pr) : "memory");
           }
           if (pr & kFuseSnap) {
+            if constexpr (kLdsSnap) {
+              const uint32_t sa = dbase + (uint32_t)(kRowUnroll * 3) * (kStripPx * 4) + lane * 48;
+              lds_write_b128(sa, u32x4{acc[0], acc[1], acc[2], acc[3]});
+              lds_write_b128(sa + 16, u32x4{acc[4], acc[5], acc[6], acc[7]});
+              lds_write_b128(sa + 32, u32x4{acc[8], acc[9], acc[10], acc[11]});
+            } else {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) snap[e] = acc[e];
+              for (int e = 0; e < 12; ++e) snap[e] = acc[e];
+            }
           }
         }
       }
@@ -2053,9 +2095,16 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
       }
       {
         f360::KernelSpan span(ctx, f360::kSatWalk, prof, n);
-        hipLaunchKernelGGL((sat_walk_kernel<kSrcRgb0, 2, true>),
-                           dim3((a.walk_units + kFuseOwners - 1) / kFuseOwners),
-                           dim3(128 * kFuseOwners), 0, ctx->stream, a, wb, wf);
+        const dim3 fgrid((a.walk_units + kFuseOwners - 1) / kFuseOwners), fblock(128 * kFuseOwners);
+        if (yuv_src == kSrcYuvSwsX86)
+          hipLaunchKernelGGL((sat_walk_kernel<kSrcYuvSwsX86, 2, true>), fgrid, fblock, 0,
+                             ctx->stream, a, wb, wf);
+        else if (yuv_src == kSrcYuvSwsC)
+          hipLaunchKernelGGL((sat_walk_kernel<kSrcYuvSwsC, 2, true>), fgrid, fblock, 0,
+                             ctx->stream, a, wb, wf);
+        else
+          hipLaunchKernelGGL((sat_walk_kernel<kSrcRgb0, 2, true>), fgrid, fblock, 0, ctx->stream,
+                             a, wb, wf);
       }
       {
         f360::KernelSpan span(ctx, f360::kWalkFuseFix, prof, n);
@@ -2087,16 +2136,24 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
 // read-once encoder would not take this call, or the frames / grid are outside what the strip
 // owners' packed bookkeeping holds; the caller then makes the two calls.
 bool f360::sat_encode_sample_applies(const f360_ctx *ctx, int count, int width, int height,
-                                     int linesize, int out_w, int out_h, int dst_linesize) {
-  return walk_wanted(ctx, count, width) && linesize / width == 4 && width % 4 == 0 &&
-         linesize % 16 == 0 && (size_t)width * height * 3 < ((size_t)1 << 31) &&
+                                     int linesize, int out_w, int out_h, int dst_linesize,
+                                     const f360::YuvPlanes *yuv) {
+  // the source side: f360_sat_encode_batch's / f360_sat_encode_yuv420p_batch's own rules
+  const bool source_ok =
+      yuv ? height % 2 == 0 && yuv->y_linesize >= width && yuv->u_linesize >= width / 2 &&
+                yuv->v_linesize >= width / 2 && yuv->y_linesize % 4 == 0 &&
+                yuv->u_linesize % 2 == 0 && yuv->v_linesize % 2 == 0
+          : linesize / width == 4 && linesize % 16 == 0;
+  return walk_wanted(ctx, count, width) && source_ok && width % 4 == 0 &&
+         (size_t)width * height * 3 < ((size_t)1 << 31) &&
          out_w < 65536 && out_h < 65536 && (width + kStripPx - 1) / kStripPx <= kFixCols / 4 &&
          dst_linesize % 4 == 0 && dst_linesize >= 4 * out_w;
 }
 int f360::sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats,
-                                 const uint8_t *const *srcs, int width, int height, int linesize,
-                                 const f360::SatFuse &fuse, bool prof) {
-  return sat_encode_walk(ctx, count, sats, srcs, nullptr, width, height, linesize, prof, &fuse);
+                                 const uint8_t *const *srcs, const f360::YuvPlanes *yuvs,
+                                 int width, int height, int linesize, const f360::SatFuse &fuse,
+                                 bool prof) {
+  return sat_encode_walk(ctx, count, sats, srcs, yuvs, width, height, linesize, prof, &fuse);
 }
 
 // Debug: the per-unit statistics of the last read-once launch that ran with debug.ablate bit 8

@@ -232,6 +232,15 @@ int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targ
                                      int target_width, int target_height, int target_linesize,
                                      int source_width, int source_height, int source_linesize,
                                      const float *centers_xy);
+/* The same from the decoder's planar YUV 4:2:0 frames (the planes of f360_sat_encode_yuv420p_batch:
+ * one linesize per plane kind for all frames): what f360_sat_encode_yuv420p_batch followed by
+ * f360_satdec_sample_rect_frames write. */
+int f360_satdec_encode_sample_frames_yuv420p(
+    f360_sat_decoder *dec, uint8_t *const *targets_dev, uint32_t *const *sats_dev,
+    const uint8_t *const *y_dev, const uint8_t *const *u_dev, const uint8_t *const *v_dev,
+    int y_linesize, int u_linesize, int v_linesize, int count, int target_width,
+    int target_height, int target_linesize, int source_width, int source_height,
+    const float *centers_xy);
 /* Fused SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for a gaze that
  * is known before the encode (the reference's offline modes read it from a trace,
  * src/run_satlogrectilinear.cc:926-938): frame -> reduced frame, the same bytes as

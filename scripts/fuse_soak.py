@@ -1,6 +1,7 @@
 """Soak of the one-pass encode + sample (f360_satdec_encode_sample_frames with the read-once
 encoder forced on) against the two calls it replaces, byte for byte, on random geometries, frame
-counts, gaze points (inside, on and beyond every edge), padded targets:
+counts, gaze points (inside, on and beyond every edge), padded targets; a third of the calls from
+planar YUV 4:2:0 frames (both libswscale models):
     python scripts/fuse_soak.py [seconds] [seed] [big]
 ("big": frames of 2560x1280 to 7680x3840, up to 5 per call -- dozens of strips, thousands of rows)"""
 import os
@@ -15,7 +16,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 t0 = time.time()
-calls = frames_done = bad = 0
+calls = frames_done = bad = planar_cases = 0
 worst = []
 with f360.Context(0) as ctx:
     ctx.set_option("sat.walk", 1)
@@ -65,10 +66,25 @@ with f360.Context(0) as ctx:
             b.fill(fill)
         for b in sats_b:
             b.fill(0xEE)
-        enc.EncodeFramesGPU([b.ptr for b in sats_a], [b.ptr for b in srcs], w, h, 4 * w)
-        dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, tl, [b.ptr for b in sats_a], (w, h), gazes)
-        dec.EncodeSampleFramesGPU([b.ptr for b in reds_b], rw, rh, tl, [b.ptr for b in sats_b],
-                                  [b.ptr for b in srcs], w, h, 4 * w, gazes)
+        planar = h % 2 == 0 and rng.integers(0, 3) == 0  # a third of the cases from planes
+        if planar:
+            planar_cases += 1
+            model = int(rng.integers(0, 2))
+            ctx.set_option("yuv.model", model)
+            cw = w // 2
+            pl = [tuple(ctx.upload(rng.integers(0, 256, shp, dtype=np.uint8))
+                        for shp in ((h, w), (h // 2, cw), (h // 2, cw))) for _ in range(n)]
+            ptrs = [(a.ptr, b.ptr, c.ptr) for (a, b, c) in pl]
+            enc.EncodeFramesYUV420PGPU([b.ptr for b in sats_a], ptrs, w, cw, cw, w, h)
+            dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, tl, [b.ptr for b in sats_a], (w, h), gazes)
+            dec.EncodeSampleFramesYUV420PGPU([b.ptr for b in reds_b], rw, rh, tl, [b.ptr for b in sats_b],
+                                             ptrs, w, cw, cw, w, h, gazes)
+            srcs = srcs + [p for t in pl for p in t]
+        else:
+            enc.EncodeFramesGPU([b.ptr for b in sats_a], [b.ptr for b in srcs], w, h, 4 * w)
+            dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, tl, [b.ptr for b in sats_a], (w, h), gazes)
+            dec.EncodeSampleFramesGPU([b.ptr for b in reds_b], rw, rh, tl, [b.ptr for b in sats_b],
+                                      [b.ptr for b in srcs], w, h, 4 * w, gazes)
         for k in range(n):
             ra, rb = reds_a[k].copy_to_host(np.uint8, (rh, tl)), reds_b[k].copy_to_host(np.uint8, (rh, tl))
             ta, tb = sats_a[k].copy_to_host(np.uint32, (h, w, 3)), sats_b[k].copy_to_host(np.uint32, (h, w, 3))
@@ -83,6 +99,6 @@ with f360.Context(0) as ctx:
             b.free()
         dec.close()
     rec = ctx.debug_walk_recoveries()
-print({"calls": calls, "frames": frames_done, "differing_frames": bad, "first_failures": worst or None,
+print({"calls": calls, "planar_calls": planar_cases, "frames": frames_done, "differing_frames": bad, "first_failures": worst or None,
        "handoff_recoveries": rec, "seconds": round(time.time() - t0, 1), "seed": seed})
 sys.exit(1 if bad else 0)

@@ -78,6 +78,15 @@ def main():
                            "_instance": inst, "_frames_per_launch": fpl}
     if len(sys.argv) >= 6:
         yf, yw = means(sys.argv[4], "FETCH_SIZE"), means(sys.argv[5], "WRITE_SIZE")
+        # the planar default command is one pass as well (its plan and fix-up kernels are the
+        # RGB0 command's); x86 rounding model = 3
+        if "sat_walk_kernel<3, 2, true>" in yf and "sat_walk_kernel<3, 2, true>" in yw:
+            doc.setdefault("sat_walk_kernel", {})[size + ":yuv420p:one_pass"] = int(
+                1024 * (2 * yf["sat_walk_kernel<3, 2, true>"] + yw["sat_walk_kernel<3, 2, true>"]) / 32)
+            for kernel in ("walk_fuse_plan_kernel", "walk_fuse_fix_kernel"):
+                if kernel in yf and kernel in yw:
+                    doc.setdefault(kernel, {})[size + ":yuv420p:one_pass"] = int(
+                        1024 * (yf[kernel] + yw[kernel]) / 32)
         # planar source, x86 rounding model = 3
         for inst, kernel, fpl in (("sat_walk_kernel<3, 2, false>", "sat_walk_kernel", 32),
                                   ("sat_write_kernel<3, 1>", "sat_write_kernel", 1),

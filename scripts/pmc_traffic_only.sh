@@ -19,4 +19,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${tag}_4 -- $B > $O/pmc
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_${tag}_5 -- $B > $O/pmc_${tag}_5.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${tag}_yuv_d4 -- $D --source yuv420p > $O/pmc_${tag}_yuv_d4.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_${tag}_yuv_d5 -- $D --source yuv420p > $O/pmc_${tag}_yuv_d5.log 2>&1 || exit 1
-python $R/scripts/pmc_traffic.py $O/${tag}_pmc_traffic.json $O/pmc_${tag}_d4:$O/pmc_${tag}_t4:$O/pmc_${tag}_4 $O/pmc_${tag}_d5:$O/pmc_${tag}_t5:$O/pmc_${tag}_5 $O/pmc_${tag}_yuv_d4 $O/pmc_${tag}_yuv_d5
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${tag}_yuv_t4 -- $T --source yuv420p > $O/pmc_${tag}_yuv_t4.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_${tag}_yuv_t5 -- $T --source yuv420p > $O/pmc_${tag}_yuv_t5.log 2>&1 || exit 1
+python $R/scripts/pmc_traffic.py $O/${tag}_pmc_traffic.json $O/pmc_${tag}_d4:$O/pmc_${tag}_t4:$O/pmc_${tag}_4 $O/pmc_${tag}_d5:$O/pmc_${tag}_t5:$O/pmc_${tag}_5 $O/pmc_${tag}_yuv_d4:$O/pmc_${tag}_yuv_t4 $O/pmc_${tag}_yuv_d5:$O/pmc_${tag}_yuv_t5

@@ -27,7 +27,8 @@ def test_single_gpu_plan_is_the_plain_command():
     # ... and the default call is the one that samples during that encoder's pass
     assert plan["ranks"][0]["one_pass"] is True
     assert dry("--one-pass", "off")["ranks"][0]["one_pass"] is False
-    assert dry("--source", "yuv420p")["ranks"][0]["one_pass"] is False
+    assert dry("--source", "yuv420p")["ranks"][0]["one_pass"] is True
+    assert dry("--opt", "fuse.walk=0")["ranks"][0]["one_pass"] is False
     assert plan["launch"][1:] == [BENCH]          # no launcher around N = 1
 
 

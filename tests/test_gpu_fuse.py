@@ -317,3 +317,50 @@ def test_two_one_pass_launches_share_the_device(f360, oracle):
     for t in threads:
         t.join()
     assert results == {0: ([], 0), 1: ([], 0)}, results
+
+
+@pytest.mark.parametrize("model,w,h,pad", [(1, 1024, 512, (0, 0, 0)), (0, 1024, 512, (0, 0, 0)),
+                                           (1, 1336, 202, (8, 4, 2)), (1, 1920, 1080, (0, 0, 0)),
+                                           (0, 520, 66, (4, 2, 6))])
+def test_encode_sample_from_planes_matches_oracle(f360, walk_ctx, oracle, model, w, h, pad):
+    """EncodeSampleFramesYUV420PGPU: the planar strip owners (conversion in registers, snapshot in
+    LDS, no source-pixel rows) against the oracle: the table of the oracle-converted frame and its
+    reduced frame at the gaze; both libswscale models, padded planes, ragged geometries."""
+    rng = np.random.default_rng(2000 + w + h + model)
+    cw = (w + 1) // 2
+    gazes = GAZES[:10]
+    n = len(gazes)
+    planes = [(rng.integers(0, 256, (h, w + pad[0]), dtype=np.uint8),
+               rng.integers(0, 256, (h // 2, cw + pad[1]), dtype=np.uint8),
+               rng.integers(0, 256, (h // 2, cw + pad[2]), dtype=np.uint8)) for _ in range(n)]
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    walk_ctx.set_option("yuv.model", model)
+    dec = f360.SATDecoder(walk_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    dev = [tuple(walk_ctx.upload(p) for p in pl) for pl in planes]
+    sats = [walk_ctx.malloc(w * h * 12) for _ in range(n)]
+    reds = [walk_ctx.malloc(rw * rh * 4) for _ in range(n)]
+    for b in sats:
+        b.fill(0xEE)
+    for b in reds:
+        b.fill(0x77)
+    y0, u0, v0 = planes[0]
+    dec.EncodeSampleFramesYUV420PGPU([b.ptr for b in reds], rw, rh, 4 * rw, [b.ptr for b in sats],
+                                     [(a.ptr, b.ptr, c.ptr) for (a, b, c) in dev], y0.shape[1],
+                                     u0.shape[1], v0.shape[1], w, h, gazes)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    bad = []
+    for k in range(n):
+        y, u, v = planes[k]
+        want_sat = oracle.sat_encode(oracle.yuv420p_to_rgb0(y, u, v, w, h, model), w, h, 4 * w)
+        want = np.full((rh, 4 * rw), 0x77, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, 4 * rw, want_sat, w, h, grid, *gazes[k])
+        if not np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want_sat):
+            bad.append(("table", k))
+        if not np.array_equal(reds[k].copy_to_host(np.uint8, (rh, 4 * rw)), want):
+            bad.append(("reduced", k, gazes[k]))
+    walk_ctx.set_option("yuv.model", 1)
+    for b in sats + reds + [p for t in dev for p in t]:
+        b.free()
+    dec.close()
+    assert bad == []
