@@ -308,7 +308,9 @@ def main():
     for d in decs:
         d.InitializeGrid(rw, rh, w, h)
     # (several streams: frames go round-robin over the contexts one call pair at a time)
-    fpc = 1 if args.fused else max(1, min(args.frames_per_call, B))
+    # (--fused from RGB0: FoveateFramesRectGPU takes the frames of a call together; from planes
+    # the fused call is per frame)
+    fpc = 1 if (args.fused and args.source == "yuv420p") else max(1, min(args.frames_per_call, B))
     # one set of tables per context: a call pair's tables live until its sample call has run
     nt_, tb = len(ctxs) * fpc, 12 * w * h
 
@@ -379,8 +381,16 @@ def main():
                 for o in range(nstreams):
                     if o != s:
                         streams[s].wait_stream(streams[o])
-                ctxs[s].profile_arm(1 if one_pass else 2)
+                ctxs[s].profile_arm(1 if (one_pass or args.fused) else 2)
             mine_sats = sat_ptr[s * fpc:s * fpc + n]
+            if args.fused:
+                decs[s].FoveateFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, frame_ptr[g:g + n],
+                                             w, h, 4 * w, gazes[g:g + n])
+                if sampled:
+                    for o in range(nstreams):
+                        if o != s:
+                            streams[o].wait_stream(streams[s])
+                continue
             if one_pass and yuv:
                 decs[s].EncodeSampleFramesYUV420PGPU(red_ptr[g:g + n], rw, rh, 4 * rw, mine_sats,
                                                      yuv_ptr[g:g + n], w, w // 2, w // 2, w, h,
@@ -504,7 +514,8 @@ def main():
         frame_bytes = (w * h * 3) // 2 if yuv else 4 * w * h
         # One pass (EncodeSampleFramesGPU): sat_walk_kernel does the sampler's work as well and is
         # charged the whole path; the row-plan and fix-up kernels around it do none of it.
-        alg = {"sat_walk_kernel": enc_bytes + (smp_bytes if one_pass_ran else 0),
+        alg = {"sat_walk_kernel": (frame_bytes + 4 * rw * rh) if args.fused
+               else enc_bytes + (smp_bytes if one_pass_ran else 0),
                "walk_fuse_plan_kernel": 0, "walk_fuse_fix_kernel": 0,
                "sat_write_kernel": frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes,
                "sat_reduce_kernel": 0, "sat_carry_kernel": 0,
@@ -540,6 +551,7 @@ def main():
         roofline_kernels = {name: roof_of(name) for name in alg if name in kernels}
         # the dominant kernel: the one that moves the table
         dom = "sat_walk_kernel" if "sat_walk_kernel" in kernels else "sat_write_kernel"
+        # (--fused in batches runs the one-pass strip walker without table stores)
         roof = roofline_kernels.get(dom)
         # whole path: SURVEY 8(d)'s figure for the two calls; fused, the table and its re-read are
         # not algorithmic work any more: frame in + reduced frame out
@@ -574,8 +586,9 @@ def main():
                                    + ", Lissajous gaze, inputs resident in HBM",
                        "source": args.source, "fused": bool(args.fused),
                        "call": ("EncodeSampleFramesYUV420PGPU" if one_pass and yuv
-                                else "EncodeSampleFramesGPU" if one_pass else "FoveateFrameRectGPU"
-                                if args.fused
+                                else "EncodeSampleFramesGPU" if one_pass
+                                else "FoveateFramesRectGPU" if args.fused and fpc > 1
+                                else "FoveateFrameRectGPU" if args.fused
                                 else ("EncodeFramesYUV420PGPU" if yuv else "EncodeFramesGPU") + " + SampleFramesRectGPU"
                                 if fpc > 1
                                 else ("EncodeFrameYUV420PGPU" if yuv else "EncodeFrameGPU") + " + SampleFrameRectGPU"),
@@ -667,6 +680,14 @@ def main():
                 return round(nsteps * B * w * h / 1e6 / (time.perf_counter() - t1), 1)
             variants = {"fused_rgb0": run_variant(lambda k: decs[0].FoveateFrameRectGPU(
                 red_ptr[k], rw, rh, 4 * rw, frame_ptr[k], w, h, 4 * w, gazes[k][0], gazes[k][1]))}
+
+            def fused_batches(k):  # reduced frames only, the call's frames together
+                if k % fpc == 0:
+                    n = min(fpc, B - k)
+                    decs[0].FoveateFramesRectGPU(red_ptr[k:k + n], rw, rh, 4 * rw, frame_ptr[k:k + n],
+                                                 w, h, 4 * w, gazes[k:k + n])
+            if fpc > 1:
+                variants["fused_rgb0_batched"] = run_variant(fused_batches)
             if w % 4 == 0 and h % 2 == 0:
                 py = torch.randint(0, 256, (B, h, w), dtype=torch.uint8, device=dev)
                 pu = torch.randint(0, 256, (B, h // 2, w // 2), dtype=torch.uint8, device=dev)

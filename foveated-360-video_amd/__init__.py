@@ -116,6 +116,9 @@ _SIGNATURES = {
     "f360_satdec_encode_sample_frames": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                                  POINTER(c_void_p), c_int, c_int, c_int, c_int,
                                                  c_int, c_int, c_int, POINTER(c_float)]),
+    "f360_satdec_foveate_rect_frames": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
+                                                c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                POINTER(c_float)]),
     "f360_satdec_encode_sample_frames_yuv420p": (c_int, [c_void_p, POINTER(c_void_p),
                                                          POINTER(c_void_p), POINTER(c_void_p),
                                                          POINTER(c_void_p), POINTER(c_void_p),
@@ -589,6 +592,22 @@ class SATDecoder:
                                                       target_height, target_linesize,
                                                       source_width, source_height,
                                                       source_linesize, xy))
+
+    def FoveateFramesRectGPU(self, cl_target_buffers, target_width, target_height,
+                             target_linesize, cl_source_frames, source_width, source_height,
+                             source_linesize, centers) -> None:
+        """FoveateFrameRectGPU for a batch of frames (f360_satdec_foveate_rect_frames): the reduced
+        frames of EncodeSampleFramesGPU without the tables."""
+        self._need("FoveateFramesRectGPU")
+        n = len(cl_target_buffers)
+        if n != len(cl_source_frames) or n != len(centers):
+            raise ValueError("FoveateFramesRectGPU: as many targets as frames and gaze points")
+        dsts = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        srcs = (c_void_p * n)(*[int(p) for p in cl_source_frames])
+        xy = (c_float * (2 * n))(*[float(v) for c in centers for v in c])
+        _check(lib().f360_satdec_foveate_rect_frames(self._h, dsts, srcs, n, target_width,
+                                                     target_height, target_linesize, source_width,
+                                                     source_height, source_linesize, xy))
 
     def EncodeSampleFramesYUV420PGPU(self, cl_target_buffers, target_width, target_height,
                                      target_linesize, cl_tables, planes, y_linesize, u_linesize,

@@ -1285,8 +1285,9 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
                                      int target_height, int target_linesize, int source_width,
                                      int source_height, int source_linesize,
                                      const float *centers_xy) {
-  F360_REQUIRE(dec && targets_dev && sats_dev && (sources_dev || planes) && centers_xy &&
-                   count >= 1,
+  // `sats_dev` null: no tables wanted (f360_satdec_foveate_rect_frames; RGB0 sources)
+  F360_REQUIRE(dec && targets_dev && (sats_dev || !planes) && (sources_dev || planes) &&
+                   centers_xy && count >= 1,
                "f360_satdec_encode_sample_frames: bad arguments");
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width &&
@@ -1300,7 +1301,7 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
                                                   source_linesize, target_width, target_height,
                                                   target_linesize, planes);
   for (int k = 0; k < count && one_pass; ++k) {
-    one_pass = targets_dev[k] && sats_dev[k] && ((uintptr_t)sats_dev[k] % 16) == 0 &&
+    one_pass = targets_dev[k] && (!sats_dev || (sats_dev[k] && ((uintptr_t)sats_dev[k] % 16) == 0)) &&
                ((uintptr_t)targets_dev[k] % 4) == 0 && std::fabs(centers_xy[2 * k]) <= 16.0f &&
                std::fabs(centers_xy[2 * k + 1]) <= 16.0f;
     if (planes)
@@ -1338,6 +1339,15 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
                                         f360::take_profile_slot(ctx));
   }
   int st;
+  if (!sats_dev) {  // reduced frames only: the single-frame fused call, frame by frame
+    for (int k = 0; k < count; ++k) {
+      st = f360_satdec_foveate_rect(dec, targets_dev[k], target_width, target_height,
+                                    target_linesize, sources_dev[k], source_width, source_height,
+                                    source_linesize, centers_xy[2 * k], centers_xy[2 * k + 1]);
+      if (st != F360_OK) return st;
+    }
+    return F360_OK;
+  }
   if (planes) {
     std::vector<const uint8_t *> y((size_t)count), u((size_t)count), v((size_t)count);
     for (int k = 0; k < count; ++k) {
@@ -1364,6 +1374,16 @@ int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targ
                                      int target_linesize, int source_width, int source_height,
                                      int source_linesize, const float *centers_xy) {
   return encode_sample_frames_impl(dec, targets_dev, sats_dev, sources_dev, nullptr, count,
+                                   target_width, target_height, target_linesize, source_width,
+                                   source_height, source_linesize, centers_xy);
+}
+
+int f360_satdec_foveate_rect_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                    const uint8_t *const *sources_dev, int count,
+                                    int target_width, int target_height, int target_linesize,
+                                    int source_width, int source_height, int source_linesize,
+                                    const float *centers_xy) {
+  return encode_sample_frames_impl(dec, targets_dev, nullptr, sources_dev, nullptr, count,
                                    target_width, target_height, target_linesize, source_width,
                                    source_height, source_linesize, centers_xy);
 }

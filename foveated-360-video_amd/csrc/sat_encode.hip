@@ -1277,7 +1277,9 @@ __global__ __launch_bounds__(FUSE ? 128 * kFuseOwners : 64 * kWalkWaves) void sa
     const bool pub = strip + 1 < a.nstrips && unit != a.walk_mute;
     const bool need = strip > 0 && !(a.ablate & 64);   // timing experiment: nobody waits
     bool alone = false;  // a hand-off wait timed out: the rest of the strip without the chain
-    const bool no_stores = a.ablate & 128;       // timing experiment: the table is not written
+    // no table wanted (f360_satdec_foveate_rect_frames: reduced frames only), or the timing
+    // experiment of the same effect
+    const bool no_stores = (a.ablate & 128) || fr.sat == nullptr;
     const unsigned long long tag = serial & kWalkTagMask;
     const int nb = a.walk_nbatches;
     // my granules; the left neighbour's are one unit earlier (strip 0 polls its own: ignored)
@@ -1628,7 +1630,8 @@ __global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__re
 // processed pixel of the other reduced rows (the plan kernel's comment), from the finished
 // table with sample_rect_kernel's arithmetic (sat_decoder.hip).
 __global__ __launch_bounds__(256) void walk_fuse_fix_kernel(const WalkBatch wb, const WalkFuse wf,
-                                                            int src_w, int src_h) {
+                                                            int src_w, int src_h,
+                                                            int src_linesize) {
   const int f = blockIdx.y;
   const int cxp = wf.cxp[f], cyp = wf.cyp[f];
   const uint32_t *sat = wb.sat[f];
@@ -1648,6 +1651,19 @@ __global__ __launch_bounds__(256) void walk_fuse_fix_kernel(const WalkBatch wb, 
   auto from_table = [&](int i, int j, const f360::AxisBox &by) {
     const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[i + 1], wf.gx[i], src_w, true);
     if (!bx.ok) return;
+    if (sat == nullptr) {  // no table was written (RGB0 sources only): the box from the pixels
+      const uint8_t *src = wb.src[f];
+      uint3 n = make_uint3(0, 0, 0);
+      for (int y = by.lo + 1; y <= by.hi; ++y)
+        for (int x = bx.lo + 1; x <= bx.hi; ++x) {
+          const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * src_linesize + 4 * x);
+          n.x += v & 0xffu;
+          n.y += (v >> 8) & 0xffu;
+          n.z += (v >> 16) & 0xffu;
+        }
+      store(i, j, f360::udiv3_exact(n, (uint32_t)((bx.hi - bx.lo) * (by.hi - by.lo))));
+      return;
+    }
     auto at = [&](int y, int x) {
       const uint32_t *p = sat + ((size_t)y * src_w + x) * 3;
       return make_uint3(p[0], p[1], p[2]);
@@ -2062,7 +2078,7 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
     for (int k = 0; k < kWalkFrames; ++k) {
       const int q = k0 + (k < n ? k : 0);
       wb.src[k] = yuvs ? yuvs[q].y : srcs[q];
-      wb.sat[k] = sats[q];
+      wb.sat[k] = sats ? sats[q] : nullptr;  // (null: one pass without tables)
       wb.u[k] = yuvs ? yuvs[q].u : nullptr;
       wb.v[k] = yuvs ? yuvs[q].v : nullptr;
     }
@@ -2111,7 +2127,7 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
         hipLaunchKernelGGL(walk_fuse_fix_kernel,
                            dim3((wf.out_h * pmax + 255) / 256 +
                                     kFixLrows * ((wf.out_w + 255) / 256), n),
-                           dim3(256), 0, ctx->stream, wb, wf, width, height);
+                           dim3(256), 0, ctx->stream, wb, wf, width, height, linesize);
       }
       continue;
     }

@@ -241,6 +241,16 @@ int f360_satdec_encode_sample_frames_yuv420p(
     int y_linesize, int u_linesize, int v_linesize, int count, int target_width,
     int target_height, int target_linesize, int source_width, int source_height,
     const float *centers_xy);
+/* The reduced frames alone: f360_satdec_encode_sample_frames without the tables (a server that
+ * only sends the reduced frame never looks at the table again, src/video_server.cc:336-345) --
+ * the batched form of f360_satdec_foveate_rect below, same bytes.  With enough RGB0 frames for the
+ * read-once encoder its strip owners run without storing their rows; otherwise the single-frame
+ * call, frame by frame. */
+int f360_satdec_foveate_rect_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
+                                    const uint8_t *const *sources_dev, int count,
+                                    int target_width, int target_height, int target_linesize,
+                                    int source_width, int source_height, int source_linesize,
+                                    const float *centers_xy);
 /* Fused SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for a gaze that
  * is known before the encode (the reference's offline modes read it from a trace,
  * src/run_satlogrectilinear.cc:926-938): frame -> reduced frame, the same bytes as

@@ -152,6 +152,24 @@ class SATDecoder {
                 << " " << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 
+  // The reduced frames alone (no tables): FoveateFrameRectGPU below for `count` frames.
+  void FoveateFramesRectGPU(int count, cl_mem const *cl_target_buffers, int target_width,
+                            int target_height, int target_linesize,
+                            cl_mem const *cl_source_frames, int source_width, int source_height,
+                            int source_linesize, const float *centers_xy) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::FoveateFramesRectGPU] Not initialized with OpenCL" << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_foveate_rect_frames(
+        impl, reinterpret_cast<uint8_t *const *>(cl_target_buffers),
+        reinterpret_cast<const uint8_t *const *>(cl_source_frames), count, target_width,
+        target_height, target_linesize, source_width, source_height, source_linesize, centers_xy);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::FoveateFramesRectGPU] kernel launch failed:" << ret << " "
+                << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
   // Not in the reference: EncodeFrameGPU + SampleFrameRectGPU fused for a gaze known before the
   // encode (its offline modes, src/run_satlogrectilinear.cc:926-938); same bytes, no table.
   void FoveateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,

@@ -1,7 +1,8 @@
 """Soak of the one-pass encode + sample (f360_satdec_encode_sample_frames with the read-once
 encoder forced on) against the two calls it replaces, byte for byte, on random geometries, frame
 counts, gaze points (inside, on and beyond every edge), padded targets; a third of the calls from
-planar YUV 4:2:0 frames (both libswscale models):
+planar YUV 4:2:0 frames (both libswscale models); the RGB0 calls also through the no-table form
+(FoveateFramesRectGPU):
     python scripts/fuse_soak.py [seconds] [seed] [big]
 ("big": frames of 2560x1280 to 7680x3840, up to 5 per call -- dozens of strips, thousands of rows)"""
 import os
@@ -85,6 +86,19 @@ with f360.Context(0) as ctx:
             dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, tl, [b.ptr for b in sats_a], (w, h), gazes)
             dec.EncodeSampleFramesGPU([b.ptr for b in reds_b], rw, rh, tl, [b.ptr for b in sats_b],
                                       [b.ptr for b in srcs], w, h, 4 * w, gazes)
+            # ... and the reduced frames alone (no tables): the same bytes once more
+            reds_c = [ctx.malloc(rh * tl) for _ in range(n)]
+            for b in reds_c:
+                b.fill(fill)
+            dec.FoveateFramesRectGPU([b.ptr for b in reds_c], rw, rh, tl, [b.ptr for b in srcs], w, h,
+                                     4 * w, gazes)
+            for k in range(n):
+                if not np.array_equal(reds_c[k].copy_to_host(np.uint8, (rh, tl)),
+                                      reds_a[k].copy_to_host(np.uint8, (rh, tl))):
+                    bad += 1
+                    if len(worst) < 10:
+                        worst.append(("no-table", w, h, n, k, gazes[k], tpad))
+            srcs = srcs + reds_c
         for k in range(n):
             ra, rb = reds_a[k].copy_to_host(np.uint8, (rh, tl)), reds_b[k].copy_to_host(np.uint8, (rh, tl))
             ta, tb = sats_a[k].copy_to_host(np.uint32, (h, w, 3)), sats_b[k].copy_to_host(np.uint32, (h, w, 3))

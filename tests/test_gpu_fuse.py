@@ -364,3 +364,43 @@ def test_encode_sample_from_planes_matches_oracle(f360, walk_ctx, oracle, model,
         b.free()
     dec.close()
     assert bad == []
+
+
+def _foveate_frames(f360, ctx, oracle, w, h, gazes, seed=400, fill=0x6B):
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    n = len(gazes)
+    frames = [oracle.lcg_frame(w, h, seed + k) for k in range(n)]
+    dec = f360.SATDecoder(ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    srcs = [ctx.upload(f) for f in frames]
+    reds = [ctx.malloc(rw * rh * 4) for _ in range(n)]
+    for b in reds:
+        b.fill(fill)
+    dec.FoveateFramesRectGPU([b.ptr for b in reds], rw, rh, 4 * rw, [b.ptr for b in srcs], w, h,
+                             4 * w, gazes)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    bad = []
+    for k in range(n):
+        want = np.full((rh, 4 * rw), fill, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, 4 * rw, oracle.sat_encode(frames[k], w, h, 4 * w),
+                                  w, h, grid, *gazes[k])
+        got = reds[k].copy_to_host(np.uint8, (rh, 4 * rw))
+        if not np.array_equal(got, want):
+            rows = np.nonzero((got != want).any(axis=1))[0]
+            bad.append((k, gazes[k], int((got != want).sum()), rows[:6].tolist()))
+    for b in srcs + reds:
+        b.free()
+    dec.close()
+    return bad
+
+
+@pytest.mark.parametrize("w,h", [(1024, 512), (1336, 203), (520, 66), (2048, 96)])
+def test_foveate_frames_without_tables_matches_oracle(f360, walk_ctx, oracle, w, h):
+    """FoveateFramesRectGPU: the one-pass strip walker with its table stores off.  The reduced rows
+    the walk cannot emit (boxes clamped at the frame's top and bottom edge) have no table to be
+    sampled from and are summed from the source pixels instead -- the gaze points put them there."""
+    assert _foveate_frames(f360, walk_ctx, oracle, w, h, GAZES) == []
+
+
+def test_foveate_frames_few_frames_take_the_single_frame_call(f360, gpu_ctx, oracle):
+    assert _foveate_frames(f360, gpu_ctx, oracle, 640, 320, GAZES[:4]) == []
