@@ -931,10 +931,15 @@ __device__ __forceinline__ void walk_alone_load_batch(const EncodeArgs &a, const
 // whose two columns lie inside the strip: (D[hi_x] - D[lo_x]) / area.  The table is written
 // exactly as before; what disappears is the sampler's pass over it (197 of its 233 MB per 8K
 // frame are table rows read back).  Which rows snapshot and which emit is a per-frame row plan
-// (walk_fuse_plan_kernel); which columns a strip owns it works out itself when it starts.  The
-// pixels this leaves out -- boxes that straddle two strips (three per strip boundary at most),
-// and reduced rows whose boxes overlap their neighbours' at the frame's top and bottom edge --
-// are sampled from the finished table by walk_fuse_fix_kernel.
+// (walk_fuse_plan_kernel).  The gathering is not done by the strip owners -- they are the serial
+// chain of the launch -- but by a helper wave per owner that takes the D rows from LDS
+// (walk_fuse_helper); which pixels a strip owns the helper works out when it starts.  What this
+// leaves out is finished by walk_fuse_fix_kernel: boxes that straddle two strips (three per strip
+// boundary at most), from the halves the two strips' helpers export, and the reduced rows whose
+// boxes overlap their neighbours' at the frame's top and bottom edge (none or one per frame),
+// from the finished table.  Sources: RGB0 (source-pixel rows for the fovea, snapshot in
+// registers) and planar YUV 4:2:0 (snapshot in LDS).  Null table pointers: the same launch
+// without the table (f360_satdec_foveate_rect_frames).
 constexpr uint32_t kFuseEmit = 1u << 31;  // row plan: this table row is the lower edge of a
                                           // reduced row (bits 0-15: which, bits 16-25: box height)
 constexpr uint32_t kFuseSnap = 1u << 30;  // row plan: snapshot this table row (after emitting)
@@ -1628,7 +1633,8 @@ __global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__re
 // What the strip owners' helpers left out: in the reduced rows they emitted, the pixels whose box
 // straddles two strips, from the D values the two strips' helpers put into the side rows; every
 // processed pixel of the other reduced rows (the plan kernel's comment), from the finished
-// table with sample_rect_kernel's arithmetic (sat_decoder.hip).
+// table with sample_rect_kernel's arithmetic (sat_decoder.hip) -- or, when no table was asked
+// for, as plain sums over the box's source pixels.
 __global__ __launch_bounds__(256) void walk_fuse_fix_kernel(const WalkBatch wb, const WalkFuse wf,
                                                             int src_w, int src_h,
                                                             int src_linesize) {
