@@ -16,7 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
-t0 = time.time()
+t0 = last_note = time.time()
 calls = frames_done = bad = planar_cases = 0
 worst = []
 with f360.Context(0) as ctx:
@@ -109,6 +109,9 @@ with f360.Context(0) as ctx:
                     worst.append((w, h, n, k, gazes[k], tpad, int((ra != rb).sum()), int((ta != tb).sum())))
         calls += 1
         frames_done += n
+        if time.time() - last_note > 60:  # (a silent GPU job looks hung to the runner)
+            last_note = time.time()
+            print(f"... {calls} calls, {frames_done} frames, {bad} differing", file=sys.stderr, flush=True)
         for b in srcs + sats_a + sats_b + reds_a + reds_b:
             b.free()
         dec.close()
