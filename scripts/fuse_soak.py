@@ -42,7 +42,9 @@ with f360.Context(0) as ctx:
         gazes = []
         for _ in range(n):
             m = rng.integers(0, 4)
-            if m == 0:
+            if rng.integers(0, 40) == 0:  # far outside: nothing, or only the wrapped columns, is processed
+                g = (float(rng.uniform(-16, 16)), float(rng.uniform(-16, 16)))
+            elif m == 0:
                 g = (float(rng.uniform(0, 1)), float(rng.uniform(0, 1)))
             elif m == 1:
                 g = (float(rng.uniform(-1.5, 2.5)), float(rng.uniform(-1.5, 2.5)))
