@@ -186,6 +186,9 @@ def main():
                          "each, keeps the fastest; read-once encoder only), separate = one torch "
                          "allocation per table, slab = one for all, separateN = one N-MiB allocation "
                          "per table")
+    ap.add_argument("--frame-placement", choices=["slab", "separate"], default="slab",
+                    help="source frames and reduced frames as one allocation each (slab) or one "
+                         "allocation per frame (separate), as a caller with one cl::Buffer per frame has them")
     ap.add_argument("--table-pitch-mb", type=int, default=0,
                     help="with --placement slab: distance between consecutive tables in MiB "
                          "(0 = the table's size)")
@@ -287,7 +290,9 @@ def main():
         planes_u = torch.empty((B, h // 2, w // 2), dtype=torch.uint8, device=dev)
         planes_v = torch.empty((B, h // 2, w // 2), dtype=torch.uint8, device=dev)
     else:
-        frames = torch.empty((B, h, w * 4), dtype=torch.uint8, device=dev)
+        frames = (torch.empty((B, h, w * 4), dtype=torch.uint8, device=dev)
+                  if args.frame_placement == "slab"
+                  else [torch.empty((h, w * 4), dtype=torch.uint8, device=dev) for _ in range(B)])
     for k, g in enumerate(mine):
         gen.manual_seed(1234 + g)
         if yuv:
@@ -352,7 +357,9 @@ def main():
         except f360.F360Error as e:  # (out of memory while drawing: plain allocations)
             keep_tables, sats = alloc_tables("separate", nt_)
             placement["chosen"] = f"separate (f360_sat_tables_alloc failed: {e})"
-    reds = torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
+    reds = (torch.zeros((B, rh, rw * 4), dtype=torch.uint8, device=dev)
+            if args.frame_placement == "slab"
+            else [torch.zeros((rh, rw * 4), dtype=torch.uint8, device=dev) for _ in range(B)])
     gazes = [lissajous(g) for g in mine]
     if yuv:
         yuv_ptr = [(planes_y[k].data_ptr(), planes_u[k].data_ptr(), planes_v[k].data_ptr())
@@ -598,6 +605,7 @@ def main():
                        # where the caller's tables lie (chosen before the timed region, see
                        # profiles/round4_table_placement.txt)
                        "table_placement": placement,
+                       "frame_placement": args.frame_placement,
                        # which encoder the encode calls took: the read-once strip walker needs
                        # enough frames per call to fill the device, below that (e.g. 8 frames per
                        # rank with --global-batch 64 on 8 GPUs) the three-kernel encoder runs
