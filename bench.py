@@ -7,8 +7,12 @@
 
 `python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself: the
 parent -- which never touches a GPU -- runs the torch.distributed.run command above as a child
-process and exits with its code.  One process per GPU.  A "step" is one pass of the hot path (SATEncoder::EncodeFrameGPU followed
-by SATDecoder::SampleFrameRectGPU, through the C ABI of libf360.so) over this rank's batch of
+process and exits with its code.  One process per GPU.  A "step" is one pass of the hot path --
+the table SATEncoder::EncodeFrameGPU builds and the reduced frame SATDecoder::SampleFrameRectGPU
+takes from it, for every frame, through the C ABI of libf360.so: by default ONE
+EncodeSampleFramesGPU call per `--frames-per-call` frames, which leaves both (DESIGN.md 4.2b);
+`--one-pass off` makes the two batched calls, `--frames-per-call 1` the reference's own pair of
+calls per frame -- over this rank's batch of
 synthetic 7680x3840 RGB0 frames, which are resident in HBM before the timed region starts
 (BASELINE.json config "7680x3840 (8K) equirect, full SAT encode -> log-rectilinear decode
 pipeline, batch=64").  By default each rank owns `--batch` distinct frames (global frame index
