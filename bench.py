@@ -317,9 +317,8 @@ def main():
     for d in decs:
         d.InitializeGrid(rw, rh, w, h)
     # (several streams: frames go round-robin over the contexts one call pair at a time)
-    # (--fused from RGB0: FoveateFramesRectGPU takes the frames of a call together; from planes
-    # the fused call is per frame)
-    fpc = 1 if (args.fused and args.source == "yuv420p") else max(1, min(args.frames_per_call, B))
+    # (--fused: FoveateFramesRect[YUV420P]GPU takes the frames of a call together)
+    fpc = max(1, min(args.frames_per_call, B))
     # one set of tables per context: a call pair's tables live until its sample call has run
     nt_, tb = len(ctxs) * fpc, 12 * w * h
 
@@ -395,8 +394,13 @@ def main():
                 ctxs[s].profile_arm(1 if (one_pass or args.fused) else 2)
             mine_sats = sat_ptr[s * fpc:s * fpc + n]
             if args.fused:
-                decs[s].FoveateFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, frame_ptr[g:g + n],
-                                             w, h, 4 * w, gazes[g:g + n])
+                if yuv:
+                    decs[s].FoveateFramesRectYUV420PGPU(red_ptr[g:g + n], rw, rh, 4 * rw,
+                                                        yuv_ptr[g:g + n], w, w // 2, w // 2, w, h,
+                                                        gazes[g:g + n])
+                else:
+                    decs[s].FoveateFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, frame_ptr[g:g + n],
+                                                 w, h, 4 * w, gazes[g:g + n])
                 if sampled:
                     for o in range(nstreams):
                         if o != s:
@@ -598,7 +602,8 @@ def main():
                        "source": args.source, "fused": bool(args.fused),
                        "call": ("EncodeSampleFramesYUV420PGPU" if one_pass and yuv
                                 else "EncodeSampleFramesGPU" if one_pass
-                                else "FoveateFramesRectGPU" if args.fused and fpc > 1
+                                else ("FoveateFramesRectYUV420PGPU" if yuv else "FoveateFramesRectGPU")
+                                if args.fused and fpc > 1
                                 else "FoveateFrameRectGPU" if args.fused
                                 else ("EncodeFramesYUV420PGPU" if yuv else "EncodeFramesGPU") + " + SampleFramesRectGPU"
                                 if fpc > 1

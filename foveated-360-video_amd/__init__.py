@@ -119,6 +119,11 @@ _SIGNATURES = {
     "f360_satdec_foveate_rect_frames": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 POINTER(c_float)]),
+    "f360_satdec_foveate_rect_frames_yuv420p": (c_int, [c_void_p, POINTER(c_void_p),
+                                                        POINTER(c_void_p), POINTER(c_void_p),
+                                                        POINTER(c_void_p), c_int, c_int, c_int,
+                                                        c_int, c_int, c_int, c_int, c_int, c_int,
+                                                        POINTER(c_float)]),
     "f360_satdec_encode_sample_frames_yuv420p": (c_int, [c_void_p, POINTER(c_void_p),
                                                          POINTER(c_void_p), POINTER(c_void_p),
                                                          POINTER(c_void_p), POINTER(c_void_p),
@@ -608,6 +613,23 @@ class SATDecoder:
         _check(lib().f360_satdec_foveate_rect_frames(self._h, dsts, srcs, n, target_width,
                                                      target_height, target_linesize, source_width,
                                                      source_height, source_linesize, xy))
+
+    def FoveateFramesRectYUV420PGPU(self, cl_target_buffers, target_width, target_height,
+                                    target_linesize, planes, y_linesize, u_linesize, v_linesize,
+                                    source_width, source_height, centers) -> None:
+        """FoveateFramesRectGPU from planar YUV 4:2:0 frames (`planes`: list of (y, u, v))."""
+        self._need("FoveateFramesRectYUV420PGPU")
+        n = len(cl_target_buffers)
+        if n != len(planes) or n != len(centers):
+            raise ValueError("FoveateFramesRectYUV420PGPU: as many targets as frames and gaze points")
+        dsts = (c_void_p * n)(*[int(p) for p in cl_target_buffers])
+        ys = (c_void_p * n)(*[int(p[0]) for p in planes])
+        us = (c_void_p * n)(*[int(p[1]) for p in planes])
+        vs = (c_void_p * n)(*[int(p[2]) for p in planes])
+        xy = (c_float * (2 * n))(*[float(v) for c in centers for v in c])
+        _check(lib().f360_satdec_foveate_rect_frames_yuv420p(
+            self._h, dsts, ys, us, vs, y_linesize, u_linesize, v_linesize, n, target_width,
+            target_height, target_linesize, source_width, source_height, xy))
 
     def EncodeSampleFramesYUV420PGPU(self, cl_target_buffers, target_width, target_height,
                                      target_linesize, cl_tables, planes, y_linesize, u_linesize,

@@ -1285,9 +1285,8 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
                                      int target_height, int target_linesize, int source_width,
                                      int source_height, int source_linesize,
                                      const float *centers_xy) {
-  // `sats_dev` null: no tables wanted (f360_satdec_foveate_rect_frames; RGB0 sources)
-  F360_REQUIRE(dec && targets_dev && (sats_dev || !planes) && (sources_dev || planes) &&
-                   centers_xy && count >= 1,
+  // `sats_dev` null: no tables wanted (f360_satdec_foveate_rect_frames[_yuv420p])
+  F360_REQUIRE(dec && targets_dev && (sources_dev || planes) && centers_xy && count >= 1,
                "f360_satdec_encode_sample_frames: bad arguments");
   F360_REQUIRE(target_width >= 1 && target_height >= 1 && source_width >= 2 &&
                    source_height >= 2 && target_linesize >= 4 * target_width &&
@@ -1341,9 +1340,15 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
   int st;
   if (!sats_dev) {  // reduced frames only: the single-frame fused call, frame by frame
     for (int k = 0; k < count; ++k) {
-      st = f360_satdec_foveate_rect(dec, targets_dev[k], target_width, target_height,
-                                    target_linesize, sources_dev[k], source_width, source_height,
-                                    source_linesize, centers_xy[2 * k], centers_xy[2 * k + 1]);
+      st = planes ? f360_satdec_foveate_rect_yuv420p(
+                        dec, targets_dev[k], target_width, target_height, target_linesize,
+                        planes[k].y, planes[k].u, planes[k].v, planes[k].y_linesize,
+                        planes[k].u_linesize, planes[k].v_linesize, source_width, source_height,
+                        centers_xy[2 * k], centers_xy[2 * k + 1])
+                  : f360_satdec_foveate_rect(dec, targets_dev[k], target_width, target_height,
+                                             target_linesize, sources_dev[k], source_width,
+                                             source_height, source_linesize, centers_xy[2 * k],
+                                             centers_xy[2 * k + 1]);
       if (st != F360_OK) return st;
     }
     return F360_OK;
@@ -1386,6 +1391,22 @@ int f360_satdec_foveate_rect_frames(f360_sat_decoder *dec, uint8_t *const *targe
   return encode_sample_frames_impl(dec, targets_dev, nullptr, sources_dev, nullptr, count,
                                    target_width, target_height, target_linesize, source_width,
                                    source_height, source_linesize, centers_xy);
+}
+
+int f360_satdec_foveate_rect_frames_yuv420p(
+    f360_sat_decoder *dec, uint8_t *const *targets_dev, const uint8_t *const *y_dev,
+    const uint8_t *const *u_dev, const uint8_t *const *v_dev, int y_linesize, int u_linesize,
+    int v_linesize, int count, int target_width, int target_height, int target_linesize,
+    int source_width, int source_height, const float *centers_xy) {
+  F360_REQUIRE(y_dev && u_dev && v_dev && count >= 1,
+               "f360_satdec_foveate_rect_frames_yuv420p: bad arguments");
+  std::vector<f360::YuvPlanes> planes((size_t)count);
+  for (int k = 0; k < count; ++k)
+    planes[(size_t)k] =
+        f360::YuvPlanes{y_dev[k], u_dev[k], v_dev[k], y_linesize, u_linesize, v_linesize};
+  return encode_sample_frames_impl(dec, targets_dev, nullptr, nullptr, planes.data(), count,
+                                   target_width, target_height, target_linesize, source_width,
+                                   source_height, 0, centers_xy);
 }
 
 int f360_satdec_encode_sample_frames_yuv420p(

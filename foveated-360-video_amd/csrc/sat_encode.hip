@@ -1635,9 +1635,12 @@ __global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__re
 // processed pixel of the other reduced rows (the plan kernel's comment), from the finished
 // table with sample_rect_kernel's arithmetic (sat_decoder.hip) -- or, when no table was asked
 // for, as plain sums over the box's source pixels.
+// (`yuv_model` -1: RGB0 sources; 0 / 1: planes, libswscale's C / x86 arithmetic)
 __global__ __launch_bounds__(256) void walk_fuse_fix_kernel(const WalkBatch wb, const WalkFuse wf,
                                                             int src_w, int src_h,
-                                                            int src_linesize) {
+                                                            int src_linesize, int yuv_model,
+                                                            const f360::YuvPlanes yl,
+                                                            const f360::YuvConsts yk) {
   const int f = blockIdx.y;
   const int cxp = wf.cxp[f], cyp = wf.cyp[f];
   const uint32_t *sat = wb.sat[f];
@@ -1657,12 +1660,21 @@ __global__ __launch_bounds__(256) void walk_fuse_fix_kernel(const WalkBatch wb, 
   auto from_table = [&](int i, int j, const f360::AxisBox &by) {
     const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[i + 1], wf.gx[i], src_w, true);
     if (!bx.ok) return;
-    if (sat == nullptr) {  // no table was written (RGB0 sources only): the box from the pixels
+    if (sat == nullptr) {  // no table was written: the box from the (converted) pixels
       const uint8_t *src = wb.src[f];
       uint3 n = make_uint3(0, 0, 0);
       for (int y = by.lo + 1; y <= by.hi; ++y)
         for (int x = bx.lo + 1; x <= bx.hi; ++x) {
-          const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * src_linesize + 4 * x);
+          uint32_t v;
+          if (yuv_model < 0) {
+            v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * src_linesize + 4 * x);
+          } else {  // (wb.src is the luma plane; the chroma sample of the 2x2 block, yuv_device.h)
+            const int Y = src[(size_t)y * yl.y_linesize + x];
+            const int U = wb.u[f][(size_t)(y >> 1) * yl.u_linesize + (x >> 1)];
+            const int V = wb.v[f][(size_t)(y >> 1) * yl.v_linesize + (x >> 1)];
+            v = yuv_model == 0 ? f360::yuv_pixel<0>(yk, Y, f360::chroma_terms<0>(yk, U, V))
+                               : f360::yuv_pixel<1>(yk, Y, f360::chroma_terms<1>(yk, U, V));
+          }
           n.x += v & 0xffu;
           n.y += (v >> 8) & 0xffu;
           n.z += (v >> 16) & 0xffu;
@@ -2133,7 +2145,8 @@ int sat_encode_walk(f360_ctx *ctx, int count, uint32_t *const *sats, const uint8
         hipLaunchKernelGGL(walk_fuse_fix_kernel,
                            dim3((wf.out_h * pmax + 255) / 256 +
                                     kFixLrows * ((wf.out_w + 255) / 256), n),
-                           dim3(256), 0, ctx->stream, wb, wf, width, height, linesize);
+                           dim3(256), 0, ctx->stream, wb, wf, width, height, linesize,
+                           !yuvs ? -1 : ctx->opt_yuv_model == 1 ? 1 : 0, a.yuv, a.k);
       }
       continue;
     }

@@ -251,6 +251,12 @@ int f360_satdec_foveate_rect_frames(f360_sat_decoder *dec, uint8_t *const *targe
                                     int target_width, int target_height, int target_linesize,
                                     int source_width, int source_height, int source_linesize,
                                     const float *centers_xy);
+/* ... and from planar YUV 4:2:0 frames (f360_satdec_foveate_rect_yuv420p for a batch). */
+int f360_satdec_foveate_rect_frames_yuv420p(
+    f360_sat_decoder *dec, uint8_t *const *targets_dev, const uint8_t *const *y_dev,
+    const uint8_t *const *u_dev, const uint8_t *const *v_dev, int y_linesize, int u_linesize,
+    int v_linesize, int count, int target_width, int target_height, int target_linesize,
+    int source_width, int source_height, const float *centers_xy);
 /* Fused SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for a gaze that
  * is known before the encode (the reference's offline modes read it from a trace,
  * src/run_satlogrectilinear.cc:926-938): frame -> reduced frame, the same bytes as

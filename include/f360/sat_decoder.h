@@ -170,6 +170,28 @@ class SATDecoder {
                 << OpenCLManager::GetCLErrorString(ret) << std::endl;
   }
 
+  // ... and from planar YUV 4:2:0 frames.
+  void FoveateFramesRectYUV420PGPU(int count, cl_mem const *cl_target_buffers, int target_width,
+                                   int target_height, int target_linesize, cl_mem const *cl_y,
+                                   cl_mem const *cl_u, cl_mem const *cl_v, int y_linesize,
+                                   int u_linesize, int v_linesize, int source_width,
+                                   int source_height, const float *centers_xy) {
+    if (!use_opencl) {
+      std::cerr << "[SATDecoder::FoveateFramesRectYUV420PGPU] Not initialized with OpenCL"
+                << std::endl;
+      return;
+    }
+    const int ret = f360_satdec_foveate_rect_frames_yuv420p(
+        impl, reinterpret_cast<uint8_t *const *>(cl_target_buffers),
+        reinterpret_cast<const uint8_t *const *>(cl_y),
+        reinterpret_cast<const uint8_t *const *>(cl_u),
+        reinterpret_cast<const uint8_t *const *>(cl_v), y_linesize, u_linesize, v_linesize, count,
+        target_width, target_height, target_linesize, source_width, source_height, centers_xy);
+    if (ret != F360_OK)
+      std::cerr << "[SATDecoder::FoveateFramesRectYUV420PGPU] kernel launch failed:" << ret << " "
+                << OpenCLManager::GetCLErrorString(ret) << std::endl;
+  }
+
   // Not in the reference: EncodeFrameGPU + SampleFrameRectGPU fused for a gaze known before the
   // encode (its offline modes, src/run_satlogrectilinear.cc:926-938); same bytes, no table.
   void FoveateFrameRectGPU(cl_mem cl_target_buffer, int target_width, int target_height,

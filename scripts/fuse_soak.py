@@ -1,8 +1,8 @@
 """Soak of the one-pass encode + sample (f360_satdec_encode_sample_frames with the read-once
 encoder forced on) against the two calls it replaces, byte for byte, on random geometries, frame
 counts, gaze points (inside, on and beyond every edge), padded targets; a third of the calls from
-planar YUV 4:2:0 frames (both libswscale models); the RGB0 calls also through the no-table form
-(FoveateFramesRectGPU):
+planar YUV 4:2:0 frames (both libswscale models); every call also through the no-table form
+(FoveateFramesRect[YUV420P]GPU):
     python scripts/fuse_soak.py [seconds] [seed] [big]
 ("big": frames of 2560x1280 to 7680x3840, up to 5 per call -- dozens of strips, thousands of rows)"""
 import os
@@ -82,7 +82,17 @@ with f360.Context(0) as ctx:
             dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, tl, [b.ptr for b in sats_a], (w, h), gazes)
             dec.EncodeSampleFramesYUV420PGPU([b.ptr for b in reds_b], rw, rh, tl, [b.ptr for b in sats_b],
                                              ptrs, w, cw, cw, w, h, gazes)
-            srcs = srcs + [p for t in pl for p in t]
+            reds_c = [ctx.malloc(rh * tl) for _ in range(n)]
+            for b in reds_c:
+                b.fill(fill)
+            dec.FoveateFramesRectYUV420PGPU([b.ptr for b in reds_c], rw, rh, tl, ptrs, w, cw, cw, w, h, gazes)
+            for k in range(n):
+                if not np.array_equal(reds_c[k].copy_to_host(np.uint8, (rh, tl)),
+                                      reds_a[k].copy_to_host(np.uint8, (rh, tl))):
+                    bad += 1
+                    if len(worst) < 10:
+                        worst.append(("no-table planar", w, h, n, k, gazes[k], tpad, model))
+            srcs = srcs + [p for t in pl for p in t] + reds_c
         else:
             enc.EncodeFramesGPU([b.ptr for b in sats_a], [b.ptr for b in srcs], w, h, 4 * w)
             dec.SampleFramesRectGPU([b.ptr for b in reds_a], rw, rh, tl, [b.ptr for b in sats_a], (w, h), gazes)

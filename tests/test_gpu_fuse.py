@@ -404,3 +404,41 @@ def test_foveate_frames_without_tables_matches_oracle(f360, walk_ctx, oracle, w,
 
 def test_foveate_frames_few_frames_take_the_single_frame_call(f360, gpu_ctx, oracle):
     assert _foveate_frames(f360, gpu_ctx, oracle, 640, 320, GAZES[:4]) == []
+
+
+@pytest.mark.parametrize("model,w,h", [(1, 1024, 512), (0, 1336, 202), (1, 520, 66)])
+def test_foveate_frames_from_planes_without_tables(f360, walk_ctx, oracle, model, w, h):
+    """FoveateFramesRectYUV420PGPU: planar strip owners, no tables; the leftover rows at the clamped
+    edges are summed from pixels converted in the fix-up kernel with the selected libswscale model."""
+    rng = np.random.default_rng(3000 + w + model)
+    cw = (w + 1) // 2
+    gazes = GAZES[:12]
+    n = len(gazes)
+    planes = [(rng.integers(0, 256, (h, w), dtype=np.uint8),
+               rng.integers(0, 256, (h // 2, cw), dtype=np.uint8),
+               rng.integers(0, 256, (h // 2, cw), dtype=np.uint8)) for _ in range(n)]
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    walk_ctx.set_option("yuv.model", model)
+    dec = f360.SATDecoder(walk_ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    dev = [tuple(walk_ctx.upload(p) for p in pl) for pl in planes]
+    reds = [walk_ctx.malloc(rw * rh * 4) for _ in range(n)]
+    for b in reds:
+        b.fill(0x19)
+    dec.FoveateFramesRectYUV420PGPU([b.ptr for b in reds], rw, rh, 4 * rw,
+                                    [(a.ptr, b.ptr, c.ptr) for (a, b, c) in dev], w, cw, cw, w, h,
+                                    gazes)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    bad = []
+    for k in range(n):
+        y, u, v = planes[k]
+        sat = oracle.sat_encode(oracle.yuv420p_to_rgb0(y, u, v, w, h, model), w, h, 4 * w)
+        want = np.full((rh, 4 * rw), 0x19, dtype=np.uint8)
+        oracle.satdec_sample_rect(want, rw, rh, 4 * rw, sat, w, h, grid, *gazes[k])
+        if not np.array_equal(reds[k].copy_to_host(np.uint8, (rh, 4 * rw)), want):
+            bad.append((k, gazes[k]))
+    walk_ctx.set_option("yuv.model", 1)
+    for b in reds + [p for t in dev for p in t]:
+        b.free()
+    dec.close()
+    assert bad == []
