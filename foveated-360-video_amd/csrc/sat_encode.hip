@@ -2282,7 +2282,10 @@ extern "C" int f360_sat_tables_alloc(f360_ctx *ctx, int width, int height, int c
   const float good_us = 80.5f * (float)((double)width * height / (7680.0 * 3840.0));
   std::vector<const uint8_t *> srcs((size_t)group);
   for (int k = 0; k < group; ++k) srcs[(size_t)k] = static_cast<const uint8_t *>(zero) + (size_t)k * fb;
-  for (int i = 0; st == F360_OK && i < nlaunch + 6; ++i) {
+  // (up to nlaunch + 12 draws: on the boxes where most allocations draw badly -- 7 of 8 at
+  // 86-94 us seen -- eight draws left a 1-in-4 chance of keeping a mediocre group; a draw is
+  // 11 GB at 8K, held until the choice is made, and running out of memory just ends the drawing)
+  for (int i = 0; st == F360_OK && i < nlaunch + 12; ++i) {
     Draw d;
     d.slab = i % 2 == 1;
     if (d.slab) {
