@@ -134,7 +134,7 @@ def launch_plan(gpus, batch, global_batch):
 
 def encoder_plan(width, frames_per_call, opts):
     """Which encoder an EncodeFramesGPU call of `frames_per_call` frames takes (the library's
-    rule, sat_encode.hip walk_wanted): the read-once strip walker needs frames x strips >=
+    rule, sat_walk.hip walk_wanted): the read-once strip walker needs frames x strips >=
     sat.walk_units (690: 23 frames at 8K) to outrun them, below that the three kernels run."""
     o = dict(kv.split("=") for kv in opts)
     walk, units = int(o.get("sat.walk", -1)), int(o.get("sat.walk_units", 690))

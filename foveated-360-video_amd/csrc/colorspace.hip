@@ -5,7 +5,7 @@
 // decoded frame with sws_getContext(w, h, yuv420p, w, h, AV_PIX_FMT_RGB0, SWS_BILINEAR) +
 // sws_scale (src/video_decoder.cc:167-170,222-224) and the server then uploads the 4-byte
 // pixels (src/video_server.cc:291-300).  With this kernel the three planes are uploaded instead
-// (1.5 instead of 4 bytes per pixel over PCIe); f360_sat_encode_yuv420p (sat_encode.hip) goes
+// (1.5 instead of 4 bytes per pixel over PCIe); f360_sat_encode_yuv420p (sat_three.hip) goes
 // one step further and never writes the RGB0 frame at all.  Arithmetic: yuv_device.h.
 #include "f360_internal.h"
 #include "host_tables.h"
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void yuv420p_to_rgb0_kernel(uint8_t *__restric
       u32x4_c{a[0] | alpha, a[1] | alpha, a[2] | alpha, a[3] | alpha};
   *reinterpret_cast<u32x4_c *>(dst + (size_t)(y0 + 1) * dst_linesize + (size_t)x0 * 4) =
       u32x4_c{b[0] | alpha, b[1] | alpha, b[2] | alpha, b[3] | alpha};
-#else  // streaming output: non-temporal, see sat_encode.hip
+#else  // streaming output: non-temporal, see sat_common.h
   __builtin_nontemporal_store(
       (u32x4_c{a[0] | alpha, a[1] | alpha, a[2] | alpha, a[3] | alpha}),
       reinterpret_cast<u32x4_c *>(dst + (size_t)y0 * dst_linesize + (size_t)x0 * 4));
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void rgb0_to_yuv420p_kernel(
 // chroma row ahead --, evaluates their luma and chroma once, and slides the window by two.
 // Stores are issued from inline asm (non-temporal, invisible to the compiler's vmcnt
 // bookkeeping: a store in the loop would otherwise turn every wait for a prefetched row into a
-// full drain, sat_encode.hip "toolchain findings").  The borders use the window as it is: row
+// full drain).  The borders use the window as it is: row
 // -1 and row `height` are loaded clamped and carry tap 0, the other taps are the folded ones.
 __device__ __forceinline__ void r2y_store8(uint8_t *base, uint32_t off, uint32_t a, uint32_t b) {
   typedef uint32_t u32x2_r __attribute__((ext_vector_type(2)));

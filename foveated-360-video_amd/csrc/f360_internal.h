@@ -81,7 +81,7 @@ struct DevBuf {
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-// Scratch of the SAT encoder for one frame geometry (see sat_encode.hip).
+// Scratch of the SAT encoder for one frame geometry (see sat_three.hip, sat_walk.hip).
 struct SatEncodePlan {
   int width = 0, height = 0;
   int band_rows = 0;   // TH: rows per band (tile height of the writer kernel)
@@ -273,7 +273,7 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
 }  // namespace f360
 
 namespace f360 {
-// Encode + sample in one pass over the frames (sat_encode.hip: sat_walk_kernel<.., true>): where
+// Encode + sample in one pass over the frames (sat_fuse.hip: sat_walk_kernel<.., true>): where
 // the reduced frames go, the gaze of every frame, the decoder's 1-D grid factors (device).
 struct SatFuse {
   uint8_t *const *dsts;

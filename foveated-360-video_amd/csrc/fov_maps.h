@@ -1,4 +1,4 @@
-// fov_maps.h -- shared by sat_decoder.hip and sat_encode.hip: one axis of the SAT sampler's box
+// fov_maps.h -- shared by sat_decoder.hip and the SAT encoders (sat_three.hip, sat_fuse.hip): one axis of the SAT sampler's box
 // rule, and the lattice maps of the fused foveation path.
 #pragma once
 
@@ -66,7 +66,7 @@ struct FovMaps {
 };
 
 // The maps of ONE axis (axis 0: x, 1: y) by one 256-thread workgroup.  Runs as two extra
-// workgroups of the reducer's launch (sat_encode.hip): the reducer does not need the maps, the
+// workgroups of the reducer's launch (sat_three.hip): the reducer does not need the maps, the
 // table writer does, so the ~13 us this used to take as a kernel of its own disappear behind
 // the reducer.  LDS: `flags` (one byte per source column / row) and `ranks` (int16), both
 // kFovLdsEntries long; longer axes use the global map in place.

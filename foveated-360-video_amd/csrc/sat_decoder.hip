@@ -22,7 +22,7 @@
 namespace {
 
 // Streaming outputs (written once, consumed later by another kernel or a copy engine) are stored
-// non-temporally: see global_store_b128_uncounted_nt in sat_encode.hip.
+// non-temporally: see global_store_b128_uncounted_nt in sat_common.h.
 #ifdef F360_NO_NT_STORES
 #define F360_STREAM_STORE(ptr, value) (*(ptr) = (value))
 #else
@@ -321,10 +321,10 @@ bool tile_stream_applies(const f360_sat_decoder *dec, const uint32_t *sat_dev, i
 // When the gaze is known before the encode (the offline modes of the reference take it from a
 // trace, run_satlogrectilinear.cc:926-938), only the table entries at the lattice rows / columns
 // that gaze samples are ever read.  foveate_maps_kernel numbers those rows and columns, the table
-// writer (sat_encode.hip, STORE == 2) emits just those entries into a compact array, and
+// writer (sat_three.hip, STORE == 2) emits just those entries into a compact array, and
 // sample_compact_kernel forms the box means from it -- the same integers as encode + sample.
 // The lattice maps as a kernel of their own (two workgroups, one per axis).  Normally they run as
-// two extra workgroups of the reducer's launch instead ("fov.piggyback", sat_encode.hip).
+// two extra workgroups of the reducer's launch instead ("fov.piggyback", sat_three.hip).
 __global__ __launch_bounds__(f360::kFovThreads) void foveate_maps_kernel(const FovMaps m) {
   __shared__ uint8_t flags[f360::kFovLdsEntries];
   __shared__ int16_t ranks[f360::kFovLdsEntries];
@@ -1320,7 +1320,7 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
     F360_REQUIRE(dec->gw == target_width && dec->gh == target_height,
                  "f360_satdec_encode_sample_frames: grid was initialised for %dx%d", dec->gw,
                  dec->gh);
-    // the row plan's reasoning (sat_encode.hip: walk_fuse_plan_kernel) and its packed fields
+    // the row plan's reasoning (sat_fuse.hip: walk_fuse_plan_kernel) and its packed fields
     auto increasing = [](const std::vector<int16_t> &g, int max_step) {
       for (size_t k = 1; k < g.size(); ++k)
         if (g[k] <= g[k - 1] || g[k] - g[k - 1] > max_step) return false;

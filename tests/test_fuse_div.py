@@ -1,4 +1,4 @@
-"""CPU tier: the float quotient of the one-pass encode + sample (sat_encode.hip: walk_fuse_rows).
+"""CPU tier: the float quotient of the one-pass encode + sample (sat_fuse_dev.h: walk_fuse_rows).
 A reduced pixel is n / (w * h) with n <= 255 * w * h, truncated; for w * h <= 2048 the helper
 wave computes it as trunc(fma(float(n), rcp(w) * rcp(h), 2^-12)).  The hardware reciprocal is good
 to one ulp, so every combination of one-ulp errors is walked here, on the operands where a wrong

@@ -1,4 +1,4 @@
-"""CPU tier: the row-plan RULE of the one-pass encode + sample (sat_encode.hip:
+"""CPU tier: the row-plan RULE of the one-pass encode + sample (sat_fuse.hip:
 walk_fuse_plan_kernel), restated and checked by simulation.
 
 A strip owner keeps ONE snapshot of its table row.  The plan kernel marks reduced row j as emitted

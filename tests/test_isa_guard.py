@@ -24,6 +24,20 @@ def test_isa_rules_hold_for_the_built_library():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+@pytest.mark.gpu
+def test_isa_rules_hold_where_the_kernels_run():
+    """The same strict check in the GPU tier: the library the parity tests of this run load is the
+    one whose hidden-store loops, counted waits, nt and sc1 bits are verified."""
+    test_isa_rules_hold_for_the_built_library()
+
+
+def test_build_honours_the_strict_switch(monkeypatch):
+    """F360_ISA_STRICT=1 makes build() pass --strict to the guard (read from the source: a real
+    build() is the driver's job)."""
+    src = open(os.path.join(REPO, "__graft_entry__.py")).read()
+    assert 'F360_ISA_STRICT' in src and '"--strict"' in src
+
+
 def test_objdump_lookup_honours_rocm_path(tmp_path, monkeypatch):
     import check_isa
     fake = tmp_path / "lib" / "llvm" / "bin"
