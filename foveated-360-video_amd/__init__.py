@@ -582,9 +582,10 @@ class SATDecoder:
                               target_linesize, cl_tables, cl_source_frames, source_width,
                               source_height, source_linesize, centers) -> None:
         """SATEncoder.EncodeFramesGPU + SampleFramesRectGPU for frames whose gaze is known before
-        the encode (f360_satdec_encode_sample_frames): the same tables and reduced frames; with
-        enough frames for the read-once encoder the reduced pixels come out of its pass and the
-        tables are not read back."""
+        the encode (f360_satdec_encode_sample_frames; the reference's offline modes,
+        run_satlogrectilinear.cc:932-938 -- its server reads the gaze after the encode and keeps
+        the two calls): the same tables and reduced frames; the reduced pixels come out of the
+        encoder's pass and no table is read back."""
         self._need("EncodeSampleFramesGPU")
         n = len(cl_target_buffers)
         if n != len(cl_tables) or n != len(cl_source_frames) or n != len(centers):

@@ -10,9 +10,11 @@ namespace f360 {
 namespace sat {
 
 // ---- encode + sample in one pass (f360_satdec_encode_sample_frames) ---------------------------
-// The gaze of every frame is known before its table is built (the server loop receives it before
-// it encodes, src/video_server.cc:287-345), and a strip owner has, at every table row, the whole
-// row of its strip in registers.  A reduced pixel is a box of the table,
+// For callers that know the gaze of a frame before its table is built -- the reference's offline
+// modes take it from a trace, src/run_satlogrectilinear.cc:932-938; its server does NOT: it
+// encodes, sleeps to the tick and then reads the latest gaze (src/video_server.cc:296-303,
+// 324-328,336) and therefore keeps the two calls -- a strip owner has, at every table row, the
+// whole row of its strip in registers.  A reduced pixel is a box of the table,
 //   (S[hi_y][hi_x] - S[lo_y][hi_x]) - (S[hi_y][lo_x] - S[lo_y][lo_x])) / area
 // (src/sat_decoder_sample_rect_kernel.cl:206-217), so a strip that keeps a copy of its table row
 // at row lo_y ("snapshot") can, at row hi_y, form D = row - snapshot and emit every reduced pixel

@@ -219,8 +219,11 @@ int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *target
                                    int source_width, int source_height,
                                    const float *centers_xy);
 /* SATEncoder::EncodeFrameGPU + SATDecoder::SampleFrameRectGPU for `count` frames whose gaze is
- * known before the encode, as in the server loop (src/video_server.cc:287-345: the gaze is
- * received, then the frame is encoded, then sampled): table k of source k AND reduced frame k at
+ * known before the encode: the reference's offline modes, which read it from a trace
+ * (src/run_satlogrectilinear.cc:932-938).  The reference's SERVER is not such a caller: it
+ * encodes, sleeps to the tick and only then reads the latest gaze
+ * (src/video_server.cc:296-303,324-328,336), so using this call there changes its control flow
+ * -- it keeps the two calls.  Table k of source k AND reduced frame k at
  * gaze k, byte for byte what f360_sat_encode_batch followed by f360_satdec_sample_rect_frames
  * write.  With enough frames for the read-once encoder (f360_sat_encode_batch's rule; RGB0
  * sources) the reduced pixels are produced during the encoder's pass, from table rows still in

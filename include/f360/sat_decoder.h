@@ -102,9 +102,11 @@ class SATDecoder {
   }
 
   // Not in the reference: SATEncoder::EncodeFramesGPU + SampleFramesRectGPU for `count` frames
-  // whose gaze is known before the encode, as in the server loop (src/video_server.cc:287-345) --
-  // the same tables and reduced frames; with enough frames for the read-once encoder the reduced
-  // pixels are produced during its pass and the tables are not read back.
+  // whose gaze is known before the encode -- the offline modes, which read it from a trace
+  // (src/run_satlogrectilinear.cc:932-938); NOT the server loop, which reads the latest gaze
+  // after the encode and the tick (src/video_server.cc:324-328) and keeps the two calls.  The
+  // same tables and reduced frames; the reduced pixels are produced during the encoder's pass
+  // (strip walker from 23 8K frames per call on, band writer below) and no table is read back.
   template <class CodecContext>
   void EncodeSampleFramesGPU(int count, cl_mem const *cl_target_buffers, int target_width,
                              int target_height, int target_linesize, cl_mem const *cl_tables,
