@@ -145,6 +145,21 @@ def encoder_plan(width, frames_per_call, opts):
     return "three kernels (reduce, carry, write)"
 
 
+def one_pass_plan(args, frames_per_call):
+    """What an EncodeSampleFramesGPU call of `frames_per_call` frames does inside the library
+    (sat_decoder.hip encode_sample_frames_impl): the strip walker's one pass where the read-once
+    encoder runs, the band writer's one pass below that, or -- options off -- the two calls."""
+    if args.fused or args.one_pass == "off" or (args.one_pass == "auto" and frames_per_call <= 1):
+        return False
+    o = dict(kv.split("=") for kv in args.opt)
+    if encoder_plan(args.width, frames_per_call, args.opt).startswith("read-once"):
+        if o.get("fuse.walk", "1") != "0":
+            return "strip walker (sat_walk_kernel<.., true>)"
+    if o.get("fuse.band", "1") != "0" and args.source == "rgb0":
+        return "band writer (sat_write_fuse_kernel)"
+    return "two calls inside the library"
+
+
 def self_launch(args, argv):
     """--gpus N > 1 without a launcher: run N fresh ranks under torch.distributed.run as a child
     process.  The parent has not imported torch or made any GPU call, and it never execs."""
@@ -213,12 +228,15 @@ def main():
     ap.add_argument("--fused", action="store_true",
                     help="FoveateFrameRectGPU (encode + sample without writing the table) instead "
                          "of the two reference calls")
-    ap.add_argument("--one-pass", choices=["on", "off"], default="on",
-                    help="on (default): one EncodeSampleFramesGPU call per group of frames -- the "
-                         "tables AND the reduced frames, the reduced pixels produced during the "
-                         "read-once encoder's pass wherever the library can (RGB0 sources, enough "
-                         "frames per call), else the two calls inside the library; off: "
-                         "EncodeFramesGPU + SampleFramesRectGPU from here")
+    ap.add_argument("--one-pass", choices=["auto", "on", "off"], default="auto",
+                    help="auto (default): one EncodeSampleFramesGPU call per group of frames when "
+                         "--frames-per-call > 1 -- the tables AND the reduced frames, the reduced "
+                         "pixels produced during the encoder's pass (a caller that knows the gaze "
+                         "before the encode: the reference's offline modes, not its server); on: "
+                         "the same call also with --frames-per-call 1; off: EncodeFramesGPU + "
+                         "SampleFramesRectGPU (or the per-frame pair) from here")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the comparison of what the timed calls wrote with the CPU oracle")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the short untimed-region measurements of the fused / planar variants")
     ap.add_argument("--share-device", action="store_true",
@@ -246,11 +264,7 @@ def main():
                        "encoder": encoder_plan(args.width, min(args.frames_per_call, len(rg)), args.opt),
                        # tables and reduced frames from one pass of the read-once encoder: only
                        # where that encoder runs (else the library makes the two calls)
-                       "one_pass": (args.one_pass == "on" and not args.fused
-                                    and min(args.frames_per_call, len(rg)) > 1
-                                    and encoder_plan(args.width, min(args.frames_per_call, len(rg)),
-                                                     args.opt).startswith("read-once")
-                                    and dict(kv.split("=") for kv in args.opt).get("fuse.walk", "1") != "0")}
+                       "one_pass": one_pass_plan(args, min(args.frames_per_call, len(rg)))}
                       for r, rg in enumerate(plan)],
             "launch": (self_launch(args, argv) if args.gpus > 1 and not launched
                        else [sys.executable, os.path.abspath(__file__)] + argv)}))
@@ -375,7 +389,9 @@ def main():
     torch.cuda.synchronize(dev)
 
     calls = [0]
-    one_pass = args.one_pass == "on" and not args.fused and fpc > 1
+    table_holds = {}  # table index -> frame index (of this rank's batch) it was last written for
+    one_pass = (not args.fused and args.one_pass != "off" and
+                (fpc > 1 or args.one_pass == "on"))
 
     def step_batched(profile):
         # frames [g, g + n) in one encode call and one sample call; --profile-every counts
@@ -393,6 +409,9 @@ def main():
                         streams[s].wait_stream(streams[o])
                 ctxs[s].profile_arm(1 if (one_pass or args.fused) else 2)
             mine_sats = sat_ptr[s * fpc:s * fpc + n]
+            if not args.fused:
+                for j in range(n):
+                    table_holds[s * fpc + j] = g + j
             if args.fused:
                 if yuv:
                     decs[s].FoveateFramesRectYUV420PGPU(red_ptr[g:g + n], rw, rh, 4 * rw,
@@ -426,7 +445,7 @@ def main():
                         streams[o].wait_stream(streams[s])
 
     def step(profile):
-        if fpc > 1:
+        if fpc > 1 or one_pass:
             return step_batched(profile)
         for k in range(B):
             s = k % nstreams
@@ -451,6 +470,7 @@ def main():
                     encs[s].EncodeFrameGPU(sat_ptr[s], frame_ptr[k], w, h, 4 * w)
                 decs[s].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[s], (w, h),
                                            gazes[k][0], gazes[k][1])
+                table_holds[s] = k
             if sampled:
                 for o in range(nstreams):
                     if o != s:
@@ -474,6 +494,16 @@ def main():
     for c in ctxs:
         c.profile_reset()
     calls[0] = 0  # the first call pair of the timed region is a sampled one, whatever K and W
+    # what the timed calls write is compared with the oracle afterwards (`verified`): the outputs
+    # of the warm-up are wiped first, so a kernel that stops storing cannot pass on old bytes
+    if not args.no_verify:
+        import ctypes
+        for r_ in (reds if isinstance(reds, list) else [reds]):
+            r_.zero_()
+        for p_ in sat_ptr:
+            f360._check(f360.lib().f360_memset(ctxs[0].handle, ctypes.c_void_p(p_), 0xEE, tb))
+        ctxs[0].finish()
+        table_holds.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -496,6 +526,61 @@ def main():
         c.finish()
         recoveries += c.debug_walk_recoveries()
 
+    # ---- what the timed calls wrote, against the CPU oracle (VERDICT r4 missing #3) ----------
+    # Reduced frames: frame 0 and the frame whose gaze lies nearest a strip boundary (a multiple
+    # of 256 source columns: the fovea's 1:1 boxes then start on the boundary); tables: those of
+    # the same rule among the frames whose tables still exist (a call's tables are reused by the
+    # next call).  Whole arrays are compared, digests are printed.  A mismatch ends the run with
+    # a non-zero status after the line is out.
+    verified = None
+    if not args.no_verify:
+        import oracle_binding as ob
+        ob.lib()
+        grid = ob.satdec_grid(rw, rh, w, h)
+        model = int(dict(kv.split("=") for kv in args.opt).get("yuv.model", 1))
+
+        def boundary_distance(k):
+            x = (gazes[k][0] * w) % 256.0
+            return min(x, 256.0 - x)
+
+        def host_frame(k):
+            if yuv:
+                return ob.yuv420p_to_rgb0(planes_y[k].cpu().numpy(), planes_u[k].cpu().numpy(),
+                                          planes_v[k].cpu().numpy(), w, h, model).reshape(-1)
+            return frames[k].cpu().numpy().reshape(-1)
+
+        def pick(cands):
+            cands = sorted(cands)
+            return sorted({cands[0], min(cands, key=boundary_distance)})
+        red_frames = pick(range(B))
+        held = {f_: t_ for t_, f_ in table_holds.items()}
+        tab_frames = pick(held.keys()) if held else []
+        checks, ok = [], True
+        for k in sorted(set(red_frames) | set(tab_frames)):
+            want_sat = ob.sat_encode(host_frame(k), w, h, 4 * w)
+            entry = {"frame": int(mine[k]), "gaze": [round(gazes[k][0], 6), round(gazes[k][1], 6)],
+                     "strip_boundary_distance_px": round(boundary_distance(k), 2)}
+            if k in tab_frames:
+                got = np.empty((h, w, 3), dtype=np.uint32)
+                f360._check(f360.lib().f360_memcpy_d2h(ctxs[0].handle, got.ctypes.data_as(ctypes.c_void_p),
+                                                       ctypes.c_void_p(sat_ptr[held[k]]), got.nbytes))
+                entry["table_equal"] = bool(np.array_equal(got, want_sat))
+                entry["table_fnv1a64"] = f"{ob.fnv1a64(got):016x}"
+                ok = ok and entry["table_equal"]
+                del got
+            if k in red_frames:
+                want = np.zeros((rh, 4 * rw), dtype=np.uint8)
+                ob.satdec_sample_rect(want, rw, rh, 4 * rw, want_sat, w, h, grid, *gazes[k])
+                got = reds[k].cpu().numpy().reshape(rh, 4 * rw)
+                entry["reduced_equal"] = bool(np.array_equal(got, want))
+                entry["reduced_fnv1a64"] = f"{ob.fnv1a64(got):016x}"
+                entry["reduced_nonzero_bytes"] = int(np.count_nonzero(got))
+                ok = ok and entry["reduced_equal"]
+            checks.append(entry)
+            del want_sat
+        verified = {"ok": ok, "against": "oracle/ (f360o_sat_encode + f360o_satdec_sample_rect), whole arrays",
+                    "outputs_wiped_before_the_timed_region": True, "frames": checks}
+
     # ---- per-kernel times of the sampled frames (HIP events on the launch stream) --------
     prof = {}
     for c in ctxs:
@@ -508,8 +593,10 @@ def main():
         for name, n in c.profile_frames().items():
             frames_of[name] = frames_of.get(name, 0) + n
     kernels = {name: {"avg_us": round(1e3 * ms / n, 2), "launches": n} for name, (ms, n) in prof.items()}
-    one_pass_ran = "walk_fuse_fix_kernel" in kernels  # the library took the one-pass form
-    encoder = 2 if args.fused else 3 if one_pass_ran else 1 if "sat_walk_kernel" in kernels else 0
+    one_pass_ran = "walk_fuse_fix_kernel" in kernels  # the library took a one-pass form:
+    band_ran = "sat_write_fuse_kernel" in kernels     # the band writer's, else the strip walker's
+    encoder = (2 if args.fused else 4 if band_ran else 3 if one_pass_ran
+               else 1 if "sat_walk_kernel" in kernels else 0)
     per_rank = sharding.gather_run(my_elapsed, B, device=dev if args.backend == "nccl" else None,
                                    encoder=encoder, recoveries=recoveries)
     for name, k in kernels.items():  # a batched call's launch covers several frames
@@ -532,14 +619,21 @@ def main():
         # bytes are overhead); the sampler is charged the distinct corners + the reduced frame.
         # In fused mode the writer emits the distinct box corners instead of the table.
         frame_bytes = (w * h * 3) // 2 if yuv else 4 * w * h
-        # One pass (EncodeSampleFramesGPU): sat_walk_kernel does the sampler's work as well and is
-        # charged the whole path; the row-plan and fix-up kernels around it do none of it.
+        # One pass (EncodeSampleFramesGPU): the kernel that writes the table emits the reduced
+        # frame as well and reads no table back, so it is charged what such a pass MUST move --
+        # frame in, table out, reduced frame out (508.5 MB at 8K) -- not SURVEY 8(d)'s two-call
+        # figure, whose 12 (Wr+1)(Hr+1) corner re-reads (110 MB) it does not perform; that figure
+        # is printed beside it as frac_survey_8d.  The row-plan
+        # and fix-up kernels around it are charged nothing.
+        one_pass_bytes = enc_bytes + 4 * rw * rh
         alg = {"sat_walk_kernel": (frame_bytes + 4 * rw * rh) if args.fused
-               else enc_bytes + (smp_bytes if one_pass_ran else 0),
+               else one_pass_bytes if one_pass_ran else enc_bytes,
+               "sat_write_fuse_kernel": one_pass_bytes,
                "walk_fuse_plan_kernel": 0, "walk_fuse_fix_kernel": 0,
                "sat_write_kernel": frame_bytes + 12 * (rw + 1) * (rh + 1) if args.fused else enc_bytes,
                "sat_reduce_kernel": 0, "sat_carry_kernel": 0,
                "sample_rect_kernel": smp_bytes}
+        survey_8d = {"sat_walk_kernel": enc_bytes + smp_bytes, "sat_write_fuse_kernel": enc_bytes + smp_bytes}
         # PMC traffic is a measurement of a particular build: profiles/pmc_traffic.json carries
         # the hash of the kernel sources it was taken on and is ignored (null) for any other
         pmc = {}
@@ -554,7 +648,8 @@ def main():
                     pmc = doc
             except Exception:
                 pmc = {}
-        size_key = f"{w}x{h}" + (":yuv420p" if yuv else "") + (":one_pass" if one_pass_ran else "")
+        size_key = (f"{w}x{h}" + (":yuv420p" if yuv else "") +
+                    (":band_one_pass" if band_ran else ":one_pass" if one_pass_ran else ""))
 
         def roof_of(name):
             k = kernels[name]
@@ -562,20 +657,38 @@ def main():
             nbytes = int(alg[name] * fpl)
             gbs = nbytes / (k["avg_us"] * 1e-6) / 1e9
             traffic = pmc.get(name, {}).get(size_key) if isinstance(pmc.get(name), dict) else None
-            return {"bound": "hbm", "kernel": name + (" (emit mode)" if args.fused and name == "sat_write_kernel" else ""),
-                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": int(traffic * fpl) if traffic is not None else None,
-                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": k["avg_us"],
-                    "frames_per_launch": fpl}
+            if traffic is None and isinstance(pmc.get(name), dict) and name in ("sat_reduce_kernel", "sat_carry_kernel"):
+                traffic = pmc[name].get(f"{w}x{h}" + (":yuv420p" if yuv else ""))  # (same kernels in every form)
+            r = {"bound": "hbm", "kernel": name + (" (emit mode)" if args.fused and name == "sat_write_kernel" else ""),
+                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(gbs / HBM_PEAK_GBS, 4),
+                 "traffic": int(traffic * fpl) if traffic is not None else None,
+                 # the same launch time against the bytes the PMC counters saw (what the memory
+                 # system really moved for this kernel; null while the PMC file is of another build)
+                 "frac_traffic": (round(traffic * fpl / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                  if traffic is not None else None),
+                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": k["avg_us"],
+                 "frames_per_launch": fpl}
+            if one_pass_ran and name in survey_8d and not args.fused:
+                r["frac_survey_8d"] = round(survey_8d[name] * fpl / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                r["algorithmic_bytes"] = ("frame in + table out + reduced frame out; frac_survey_8d "
+                                          "charges SURVEY 8(d)'s two-call figure, which includes "
+                                          "12 (Wr+1)(Hr+1) bytes of corner re-reads this kernel does not make")
+            return r
         roofline_kernels = {name: roof_of(name) for name in alg if name in kernels}
         # the dominant kernel: the one that moves the table
-        dom = "sat_walk_kernel" if "sat_walk_kernel" in kernels else "sat_write_kernel"
+        dom = ("sat_walk_kernel" if "sat_walk_kernel" in kernels
+               else "sat_write_fuse_kernel" if band_ran else "sat_write_kernel")
         # (--fused in batches runs the one-pass strip walker without table stores)
         roof = roofline_kernels.get(dom)
         # whole path: SURVEY 8(d)'s figure for the two calls; fused, the table and its re-read are
         # not algorithmic work any more: frame in + reduced frame out
-        path_bytes = (frame_bytes + 4 * rw * rh) if args.fused else enc_bytes + smp_bytes
+        path_bytes = ((frame_bytes + 4 * rw * rh) if args.fused
+                      else one_pass_bytes if one_pass_ran else enc_bytes + smp_bytes)
+        survey_path_bytes = enc_bytes + smp_bytes
+
+        def frac_of(nbytes, mpix_s):  # bytes per frame at a rate in Mpixels/s, against the peak
+            return round(nbytes * mpix_s * 1e6 / (w * h) / 1e9 / HBM_PEAK_GBS, 4)
         per_frame_traffic = [pmc.get(name, {}).get(size_key) if isinstance(pmc.get(name), dict) else None
                              for name in kernels if name in alg]
         path_traffic = (int(sum(per_frame_traffic))
@@ -629,44 +742,66 @@ def main():
                        "parallelism": f"frames sharded x{world}"},
             "roofline": roof,
             "roofline_kernels": roofline_kernels,
-            "path_hbm_frac": round(path_bytes * (total_px / (w * h)) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-            # measured HBM-side bytes of one frame's pass over the path (sum of the kernels' PMC
-            # traffic, profiles/pmc_traffic.json) next to the algorithmic bytes path_hbm_frac uses
+            # whole path, per GPU: the bytes the measured call shape must move per frame (two
+            # calls: SURVEY 8(d)'s 618.5 MB at 8K; one pass: 508.5 MB, no corner re-reads) ...
+            "path_hbm_frac": frac_of(path_bytes, value / world),
+            # ... SURVEY 8(d)'s two-call figure whatever the shape (what r4 printed as path_hbm_frac) ...
+            "path_hbm_frac_survey_8d": frac_of(survey_path_bytes, value / world) if not args.fused else None,
+            # ... and the bytes the PMC counters saw (sum of the kernels' traffic per frame)
+            "path_hbm_frac_traffic": frac_of(path_traffic, value / world) if path_traffic else None,
             "path_traffic": path_traffic,
             "path_algorithmic_bytes": int(path_bytes),
+            "path_survey_8d_bytes": int(survey_path_bytes),
             "handoff_recoveries": recoveries,
+            "verified": verified,
             "kernels": kernels,
         }
         if world > 1:  # a straggler is visible: every rank's frames, ms per step and encoder
             line["per_rank"] = [{"rank": r, "frames": n, "ms_per_step": round(1e3 * t / args.steps, 4),
                                  "encoder": sharding.ENCODERS[e], "handoff_recoveries": rc}
                                 for r, n, t, e, rc in per_rank]
-        if world == 1 and not args.fused and fpc > 1 and not args.no_variants:
-            # The reference's own call shape on the same frames, outside the timed region: one
-            # EncodeFrameGPU + one SampleFrameRectGPU per frame (src/video_server.cc:300,336)
-            def per_frame_pair(k):
-                if yuv:
-                    encs[0].EncodeFrameYUV420PGPU(sat_ptr[0], *yuv_ptr[k], w, w // 2, w // 2, w, h)
-                else:
-                    encs[0].EncodeFrameGPU(sat_ptr[0], frame_ptr[k], w, h, 4 * w)
-                decs[0].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[0], (w, h),
-                                           gazes[k][0], gazes[k][1])
-            for k in range(B):
-                per_frame_pair(k)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(3):
+        if world == 1 and not args.fused and not args.no_variants:
+            # The call shapes a caller of the reference can reach, side by side and on the same
+            # frames: `value` above is the timed one; the others are
+            # measured here, after the timed region, a few steps each.
+            #   per_frame_pair : one EncodeFrameGPU + one SampleFrameRectGPU per frame -- the
+            #       reference's own loops, UNCHANGED (server: video_server.cc:300,336, gaze read
+            #       between the two; offline tool: run_satlogrectilinear.cc:926-938)
+            #   per_frame_one_pass : one EncodeSampleFramesGPU call per frame -- the offline tool
+            #       with its two calls merged (it has the trace gaze before the encode); NOT the
+            #       server, which reads the gaze after the encode
+            #   two_calls_batched : EncodeFramesGPU + SampleFramesRectGPU over `frames_per_call`
+            #       frames -- any caller that holds a queue of frames; gaze needed at sample time
+            #   one_pass_batched : one EncodeSampleFramesGPU call over `frames_per_call` frames --
+            #       a caller with a queue of frames AND their gazes (offline modes)
+            def timed(call, nsteps):
+                call()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(nsteps):
+                    call()
+                torch.cuda.synchronize(dev)
+                return nsteps * B * w * h / 1e6 / (time.perf_counter() - t1)
+
+            def per_frame_pair():
                 for k in range(B):
-                    per_frame_pair(k)
-            torch.cuda.synchronize(dev)
-            ref_value = 3 * B * w * h / 1e6 / (time.perf_counter() - t1)
-            line["value_reference_call_shape"] = round(ref_value, 1)
-            line["reference_call_shape"] = ("one EncodeFrameGPU + one SampleFrameRectGPU per frame "
-                                            "(src/video_server.cc:300,336), 3 steps after the timed "
-                                            "region; path_hbm_frac "
-                                            f"{path_bytes * ref_value * 1e6 / (w * h) / 1e9 / HBM_PEAK_GBS:.4f}")
-        if world == 1 and one_pass and not args.no_variants:
-            # the two calls on the same frames, outside the timed region
+                    if yuv:
+                        encs[0].EncodeFrameYUV420PGPU(sat_ptr[0], *yuv_ptr[k], w, w // 2, w // 2, w, h)
+                    else:
+                        encs[0].EncodeFrameGPU(sat_ptr[0], frame_ptr[k], w, h, 4 * w)
+                    decs[0].SampleFrameRectGPU(red_ptr[k], rw, rh, 4 * rw, sat_ptr[0], (w, h),
+                                               gazes[k][0], gazes[k][1])
+
+            def per_frame_one_pass():
+                for k in range(B):
+                    if yuv:
+                        decs[0].EncodeSampleFramesYUV420PGPU(red_ptr[k:k + 1], rw, rh, 4 * rw, sat_ptr[:1],
+                                                             yuv_ptr[k:k + 1], w, w // 2, w // 2, w, h,
+                                                             gazes[k:k + 1])
+                    else:
+                        decs[0].EncodeSampleFramesGPU(red_ptr[k:k + 1], rw, rh, 4 * rw, sat_ptr[:1],
+                                                      frame_ptr[k:k + 1], w, h, 4 * w, gazes[k:k + 1])
+
             def two_calls():
                 for g in range(0, B, fpc):
                     n = min(fpc, B - g)
@@ -677,18 +812,53 @@ def main():
                         encs[0].EncodeFramesGPU(sat_ptr[:n], frame_ptr[g:g + n], w, h, 4 * w)
                     decs[0].SampleFramesRectGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n], (w, h),
                                                 gazes[g:g + n])
-            two_calls()
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                two_calls()
-            torch.cuda.synchronize(dev)
-            two_value = 5 * B * w * h / 1e6 / (time.perf_counter() - t1)
-            line["value_two_calls"] = round(two_value, 1)
-            line["two_calls"] = (("EncodeFramesYUV420PGPU" if yuv else "EncodeFramesGPU") +
-                                 " + SampleFramesRectGPU on the same frames, 5 steps "
-                                 "after the timed region; path_hbm_frac "
-                                 f"{path_bytes * two_value * 1e6 / (w * h) / 1e9 / HBM_PEAK_GBS:.4f}")
+
+            def one_pass_calls():
+                for g in range(0, B, fpc):
+                    n = min(fpc, B - g)
+                    if yuv:
+                        decs[0].EncodeSampleFramesYUV420PGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n],
+                                                             yuv_ptr[g:g + n], w, w // 2, w // 2, w, h,
+                                                             gazes[g:g + n])
+                    else:
+                        decs[0].EncodeSampleFramesGPU(red_ptr[g:g + n], rw, rh, 4 * rw, sat_ptr[:n],
+                                                      frame_ptr[g:g + n], w, h, 4 * w, gazes[g:g + n])
+
+            timed_shape = ("per_frame_one_pass" if one_pass and fpc == 1 else "one_pass_batched" if one_pass
+                           else "per_frame_pair" if fpc == 1 else "two_calls_batched")
+            shapes = {}
+
+            def shape(name, call, nsteps, nbytes, reach):
+                v = value if name == timed_shape else timed(call, nsteps)
+                shapes[name] = {"mpix_per_s": round(v, 1), "us_per_frame": round(w * h / v, 2),
+                                "bytes_per_frame": int(nbytes), "path_hbm_frac": frac_of(nbytes, v),
+                                "path_hbm_frac_survey_8d": frac_of(survey_path_bytes, v),
+                                "timed_region": name == timed_shape, "reachable_from": reach}
+            shape("per_frame_pair", per_frame_pair, 3, survey_path_bytes,
+                  "the reference's loops unchanged: video_server.cc:300,336 (gaze read between the "
+                  "two calls) and run_satlogrectilinear.cc:926-938")
+            one_pass_opts = dict(kv.split("=") for kv in args.opt)
+            shape("per_frame_one_pass", per_frame_one_pass, 3,
+                  one_pass_bytes if one_pass_opts.get("fuse.band", "1") != "0" and not yuv else survey_path_bytes,
+                  "the offline tool with its two calls merged into one (trace gaze known before the "
+                  "encode, run_satlogrectilinear.cc:932-938); not the server")
+            if fpc > 1:
+                shape("two_calls_batched", two_calls, 5, survey_path_bytes,
+                      f"a caller holding {fpc} decoded frames; the gaze is needed at sample time only")
+                shape("one_pass_batched", one_pass_calls, 5,
+                      one_pass_bytes if (one_pass_ran or timed_shape != "one_pass_batched") else survey_path_bytes,
+                      f"a caller holding {fpc} decoded frames AND their gazes (offline modes); not the server")
+            line["call_shapes"] = shapes
+            # (the names r4's line used)
+            line["value_reference_call_shape"] = shapes["per_frame_pair"]["mpix_per_s"]
+            line["reference_call_shape"] = ("one EncodeFrameGPU + one SampleFrameRectGPU per frame "
+                                            "(src/video_server.cc:300,336); path_hbm_frac "
+                                            f"{shapes['per_frame_pair']['path_hbm_frac']:.4f}")
+            if "two_calls_batched" in shapes:
+                line["value_two_calls"] = shapes["two_calls_batched"]["mpix_per_s"]
+                line["two_calls"] = (("EncodeFramesYUV420PGPU" if yuv else "EncodeFramesGPU") +
+                                     " + SampleFramesRectGPU on the same frames; path_hbm_frac "
+                                     f"{shapes['two_calls_batched']['path_hbm_frac']:.4f}")
         if world == 1 and not args.no_variants and not args.fused and not yuv:
             # Outside the timed region, for information: the same frames through the fused call
             # (same bytes out, no table) and from planar YUV 4:2:0; a few steps each.
@@ -738,6 +908,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(w, h, rw, rh)
         print(json.dumps(line), flush=True)
 
+    if verified is not None and not verified["ok"]:
+        print(f"bench.py: rank {rank}: the timed calls' outputs differ from the oracle: "
+              f"{json.dumps(verified['frames'])}", file=sys.stderr)
     for d in decs:
         d.close()
     if sats is None:
@@ -747,6 +920,8 @@ def main():
         c.close()
     if world > 1:
         dist.destroy_process_group()
+    if verified is not None and not verified["ok"]:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -150,6 +150,7 @@ enum KernelId {
   kExpand,
   kWalkFusePlan,
   kWalkFuseFix,
+  kSatWriteFuse,
   kKernelCount
 };
 struct ProfSpan {
@@ -178,6 +179,7 @@ struct f360_ctx {
   int opt_interp_staged = 1;   // "interp.staged": the un-warp computes the vertical lerps once per reduced column (wave-private LDS) instead of per output pixel
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_r2y_rows = 0;        // "yuv.r2y_rows": chroma rows a wave of the RGB0 -> yuv420p converter walks down; 0 = by frame size (16 / 8 / 4, small frames: the kernel with one chroma row per thread), -1 = always that kernel
+  int opt_fuse_force = 0;      // "debug.fuse_force": tests only -- force the one-pass forms' rare branches (results stay exact): bit 0 = side rows of one pixel (more straddling boxes than they hold: the fix-up takes every row), bit 1 = no listed leftover rows (the fix-up finds them itself)
   int opt_walk_spin = 0;       // "debug.walk_spin": polls a strip's hand-off wait may take before it finishes alone; 0 = 65536
   int opt_walk_mute = 0;       // "debug.walk_mute": test only -- unit (value - 1) of every read-once launch publishes no hand-off, so its right neighbour times out; 0 = none
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results
@@ -187,6 +189,7 @@ struct f360_ctx {
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos)
   int opt_gnomonic_guard = 1;  // "gnomonic.guard": texel indices from a cheap float evaluation wherever its error bound decides them, the exact chain for the others (64 at a time)
   int opt_fuse_walk = 1;       // "fuse.walk": f360_satdec_encode_sample_frames samples inside the read-once encoder's pass wherever it applies; 0 = always the two calls
+  int opt_fuse_band = 1;       // "fuse.band": f360_satdec_encode_sample_frames calls too small for the read-once encoder sample inside the three-kernel encoder's table writer (sat_write_fuse_kernel); 0 = the two calls
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
@@ -261,6 +264,7 @@ struct SatEmit {
   int corner_stride;
   const FovMaps *maps;  // non-null: the reducer's launch also computes the lattice maps
 };
+struct SatBandFuse;  // sat_fuse_dev.h: the table writer also emits the reduced pixels of its tile
 // `yuv` non-null: the pixels come from three planes (src_dev / linesize unused)
 // `count` > 0: a batch of frames of one geometry (tables sats[k] of sources srcs[k]; sat_dev /
 // src_dev unused, no emit; `yuvs` non-null: frame k's planes, all with yuvs[0]'s linesizes).  `profile`: -1 = take a profile slot if one is armed,
@@ -269,7 +273,7 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
                     int count = 0, uint32_t *const *sats = nullptr,
                     const uint8_t *const *srcs = nullptr, int profile = -1,
-                    const YuvPlanes *yuvs = nullptr);
+                    const YuvPlanes *yuvs = nullptr, const SatBandFuse *band_fuse = nullptr);
 }  // namespace f360
 
 namespace f360 {
@@ -289,6 +293,13 @@ bool sat_encode_sample_applies(const f360_ctx *ctx, int count, int width, int he
 int sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats,
                            const uint8_t *const *srcs, const YuvPlanes *yuvs, int width,
                            int height, int linesize, const SatFuse &fuse, bool prof);
+// The same for calls the read-once encoder does not take (1 .. 22 8K frames): the three-kernel
+// encoder with its table writer in one-pass form (sat_band_fuse.hip); RGB0 frames.
+bool sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int height, int linesize,
+                                    int out_w, int out_h, int dst_linesize);
+int sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats,
+                           const uint8_t *const *srcs, int width, int height, int linesize,
+                           const SatFuse &fuse, bool prof);
 }  // namespace f360
 
 struct f360_event {

@@ -276,6 +276,8 @@ static const OptionSlot kOptions[] = {
     {"yuv.r2y_rows", &f360_ctx::opt_r2y_rows},
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
     {"fuse.walk", &f360_ctx::opt_fuse_walk},
+    {"fuse.band", &f360_ctx::opt_fuse_band},
+    {"debug.fuse_force", &f360_ctx::opt_fuse_force},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},
     {"is.lp_table", &f360_ctx::opt_lp_table},
@@ -344,7 +346,8 @@ static const char *const kKernelNames[f360::kKernelCount] = {
     "is_interpolate_logpolar_kernel", "is_blur_kernel",   "gnomonic_kernel",
     "foveate_maps_kernel",      "sample_compact_kernel",  "yuv420p_to_rgb0_kernel",
     "rgb0_to_yuv420p_kernel",   "expand_kernel",          "walk_fuse_plan_kernel",
-    "walk_fuse_fix_kernel"};
+    "walk_fuse_fix_kernel",
+    "sat_write_fuse_kernel"};
 
 int f360_kernel_count(void) { return f360::kKernelCount; }
 

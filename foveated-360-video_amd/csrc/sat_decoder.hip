@@ -1295,10 +1295,17 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
   F360_REQUIRE(f360::dims_ok({target_width, target_height, source_width, source_height}),
                "f360_satdec_encode_sample_frames: a dimension exceeds 65536");
   f360_ctx *ctx = dec->ctx;
-  bool one_pass = ctx->opt_fuse_walk != 0 &&
-                  f360::sat_encode_sample_applies(ctx, count, source_width, source_height,
-                                                  source_linesize, target_width, target_height,
-                                                  target_linesize, planes);
+  // two one-pass forms: the strip walker's wherever the read-once encoder takes the call, the
+  // band writer's (RGB0 frames, tables wanted) for calls too small for that -- from one frame up
+  const bool walks = ctx->opt_fuse_walk != 0 &&
+                     f360::sat_encode_sample_applies(ctx, count, source_width, source_height,
+                                                     source_linesize, target_width, target_height,
+                                                     target_linesize, planes);
+  const bool bands = !walks && !planes && sats_dev &&
+                     f360::sat_encode_sample_band_applies(ctx, source_width, source_height,
+                                                          source_linesize, target_width,
+                                                          target_height, target_linesize);
+  bool one_pass = walks || bands;
   for (int k = 0; k < count && one_pass; ++k) {
     one_pass = targets_dev[k] && (!sats_dev || (sats_dev[k] && ((uintptr_t)sats_dev[k] % 16) == 0)) &&
                ((uintptr_t)targets_dev[k] % 4) == 0 && std::fabs(centers_xy[2 * k]) <= 16.0f &&
@@ -1333,6 +1340,10 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
     const f360::SatFuse fuse{targets_dev, centers_xy, dec->gx_dev.as<int16_t>(),
                              dec->gy_dev.as<int16_t>(), target_width, target_height,
                              target_linesize};
+    if (bands)
+      return f360::sat_encode_sample_band(ctx, count, sats_dev, sources_dev, source_width,
+                                          source_height, source_linesize, fuse,
+                                          f360::take_profile_slot(ctx));
     return f360::sat_encode_sample_walk(ctx, count, sats_dev, sources_dev, planes, source_width,
                                         source_height, source_linesize, fuse,
                                         f360::take_profile_slot(ctx));

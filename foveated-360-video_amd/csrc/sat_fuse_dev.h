@@ -49,12 +49,28 @@ struct WalkFuse {
   uint32_t *spix, *side;
   int pmax;
   size_t side_stride;  // dwords per frame
+  int lrows_max;       // reduced rows the fix-up can take from a list (more: it takes every row)
+  // the band writer's one pass (sat_band_fuse.hip): rows per band, the per-strip pixel lists
+  int band_rows;
+  uint32_t *ent;  // [frame][strip][kBandEntStride]
 };
 constexpr int kFixCols = 256;  // straddling pixels of a frame: <= 3 per strip boundary
 constexpr int kSpixWords = 1024;  // 1 + 3 * kFixCols, rounded up; the tail: reduced rows the walk
-constexpr int kSpixLrows = 800;   // cannot emit ({count, rows}), at most kFixLrows listed
-constexpr int kFixLrows = 16;
+constexpr int kSpixLrows = 800;   // cannot emit ({count, rows}), at most WalkFuse::lrows_max listed
+constexpr int kFixLrowsWalk = 16;   // strip walker: rows clamped onto the frame's edges, 0 or 1 at 8K
+constexpr int kFixLrowsBand = 200;  // band writer: also one box per band boundary at most
+constexpr int kBandEntHead = 64;    // words of a strip's pixel list before its entries
+constexpr int kBandEntStride = kBandEntHead + 3 * 256;
 struct WalkNoFuse {};
+}  // namespace sat
+// what sat_encode_impl hands to the table writer's launch in one-pass form (sat_band_fuse.hip)
+struct SatBandFuse {
+  sat::WalkFuse wf;
+  int frame0;  // index of the launch's first frame in wf's per-frame arrays
+};
+namespace sat {
+void launch_write_fuse(f360_ctx *ctx, const EncodeArgs &a, const EncodeBatch &eb, dim3 grid,
+                       const f360::SatBandFuse &bf);
 template <bool FUSE> struct WalkFuseArg { typedef WalkNoFuse type; };
 template <> struct WalkFuseArg<true> { typedef WalkFuse type; };
 

@@ -577,7 +577,7 @@ namespace f360 {
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
                     int count, uint32_t *const *sats, const uint8_t *const *srcs, int profile,
-                    const YuvPlanes *yuvs) {
+                    const YuvPlanes *yuvs, const SatBandFuse *band_fuse) {
   F360_REQUIRE(ctx, "f360_sat_encode: null context");
   F360_BIND_DEVICE(ctx);
   if (count > 0) {
@@ -712,7 +712,13 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                        dim3(sa.nblocks + sb.nblocks + sc.nblocks, frames), dim3(256), 0,
                        ctx->stream, sa, sb, sc, p.ws_stride);
   }
-  {
+  if (band_fuse) {  // the writer also emits the reduced pixels of its tile (sat_band_fuse.hip)
+    F360_REQUIRE(vec && !emit && count > 0, "sat_encode_impl: the one-pass writer takes batches of aligned RGB0 frames");
+    f360::KernelSpan span(ctx, f360::kSatWriteFuse, prof, (int)frames);
+    launch_write_fuse(ctx, a, eb,
+                      dim3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock, frames),
+                      *band_fuse);
+  } else {
     f360::KernelSpan span(ctx, f360::kSatWrite, prof, (int)frames);
     const dim3 grid3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock, frames);
     if (yuv_src == kSrcYuvSwsX86 && emit)

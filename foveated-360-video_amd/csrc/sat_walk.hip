@@ -50,7 +50,7 @@ int walk_prepare(f360_ctx *ctx, int count, const f360::YuvPlanes *yuvs, int widt
   const size_t chain_bytes = gran_bytes + (size_t)per_launch * nstrips * 64;
   // encode + sample: a row plan per frame of a launch (one word per table row, whole batches)
   const int plan_stride = nb * kRowUnroll;
-  const int pmax = std::max(1, std::min(3 * (nstrips - 1), kFixCols));
+  const int pmax = (ctx->opt_fuse_force & 1) ? 1 : std::max(1, std::min(3 * (nstrips - 1), kFixCols));
   const size_t side_stride = fuse ? (size_t)fuse->out_h * pmax * 6 : 0;  // dwords per frame
   const size_t plan_words = (size_t)per_launch * plan_stride;
   const size_t plan_bytes =

@@ -37,7 +37,8 @@ def reduce_run(elapsed_s: float, pixels: float, device=None):
 
 
 ENCODERS = ("three kernels (reduce, carry, write)", "read-once (sat_walk_kernel)",
-            "fused (emit mode)", "one pass (sat_walk_kernel with helper waves: tables + reduced frames)")
+            "fused (emit mode)", "one pass (sat_walk_kernel with helper waves: tables + reduced frames)",
+            "one pass (three kernels, the table writer sat_write_fuse_kernel emits the reduced frame)")
 
 
 def gather_run(elapsed_s: float, frames: int, device=None, encoder: int = 0, recoveries: int = 0):

@@ -25,10 +25,16 @@ def test_single_gpu_plan_is_the_plain_command():
     # 64 frames per encode call fill the device: the read-once encoder
     assert plan["ranks"][0]["frames_per_call"] == 64 and "read-once" in plan["ranks"][0]["encoder"]
     # ... and the default call is the one that samples during that encoder's pass
-    assert plan["ranks"][0]["one_pass"] is True
+    assert plan["ranks"][0]["one_pass"].startswith("strip walker")
     assert dry("--one-pass", "off")["ranks"][0]["one_pass"] is False
-    assert dry("--source", "yuv420p")["ranks"][0]["one_pass"] is True
-    assert dry("--opt", "fuse.walk=0")["ranks"][0]["one_pass"] is False
+    assert dry("--source", "yuv420p")["ranks"][0]["one_pass"].startswith("strip walker")
+    # (the strip walker's form switched off: the band writer's takes the call)
+    assert dry("--opt", "fuse.walk=0")["ranks"][0]["one_pass"].startswith("band writer")
+    assert dry("--opt", "fuse.walk=0", "--opt", "fuse.band=0")["ranks"][0]["one_pass"] == \
+        "two calls inside the library"
+    # one frame per call: the reference's pair unless the one-pass call is asked for
+    assert dry("--frames-per-call", "1")["ranks"][0]["one_pass"] is False
+    assert dry("--frames-per-call", "1", "--one-pass", "on")["ranks"][0]["one_pass"].startswith("band writer")
     assert plan["launch"][1:] == [BENCH]          # no launcher around N = 1
 
 
@@ -38,7 +44,7 @@ def test_global_batch_64_over_8_gpus_is_8_frames_each():
     assert [r["frames"] for r in plan["ranks"]] == [[8 * k, 8 * k + 8] for k in range(8)]
     # 8 frames per rank = 240 strips: too few for the strip walker, the three kernels take them
     assert all(r["frames_per_call"] == 8 and r["encoder"].startswith("three kernels")
-               and r["one_pass"] is False for r in plan["ranks"])
+               and r["one_pass"].startswith("band writer") for r in plan["ranks"])
     cmd = plan["launch"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
