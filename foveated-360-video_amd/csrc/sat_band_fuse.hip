@@ -20,9 +20,12 @@
 //   * A tile starts with the table row above its band as its snapshot (the prologue computes
 //     that row anyway), so every box whose rows lie inside one band is emitted; a box that
 //     crosses a band boundary -- at most one per boundary, none in the fovea -- is left to the
-//     fix-up kernel, which samples it from the finished table (walk_fuse_plan_kernel<true>).
-//   * Which reduced pixels a strip owns is listed once per frame by the plan kernel, not worked
-//     out per tile (a strip has 60 tiles at 8K).
+//     fix-up kernel, which samples it from the finished table (band_fuse_plan_kernel).
+//   * Which reduced pixels a strip owns is worked out once per frame by the plan kernel, not per
+//     tile (a strip has 60 tiles at 8K) -- and a box one column wide (three quarters of an 8K
+//     frame's reduced columns, all of the fovea) needs no gather at all: the lane that holds its
+//     column has both of its columns in registers, or gets the left one from its neighbour.
+//     Only the wider boxes go through a D row in LDS.
 // Boxes that straddle two strips and the rows the plan could not mark go through the same side
 // rows and the same fix-up kernel as the strip walker's (sat_fuse_kernels.h).
 #include "sat_fuse_kernels.h"
@@ -32,62 +35,158 @@ using namespace f360::sat;
 
 namespace {
 
-// One row of a tile turned into reduced pixels.  `dlds`: the wave's D row (3 KiB, 12 bytes per
-// column), `plds`: the row's source pixels (1 KiB) -- both written by the caller just before --
-// `elds`: the strip's pixel list as the prologue left it, 8 bytes per pixel:
-//   {hi * 12 | lo * 12 << 12 | width << 24,  reduced column * 4 | hi << 22}
-// in rounds of 64, the boxes one column wide first (`n_unit` of them).  Rounds run one after the
-// other, one LDS round trip each: a tile shares its SIMD with other tiles' waves, which is what
-// hides the round trips -- keeping all rounds in registers as the strip walker's helper does
-// costs 300 VGPRs here, i.e. one wave per SIMD.
-__device__ __forceinline__ void band_emit_row(uint32_t pr, const WalkFuse &wf, uint8_t *dst,
-                                              uint32_t dlds, uint32_t plds, uint32_t elds,
-                                              int lane, int n_ent, int n_unit, uint32_t max_dxw,
-                                              bool exports, const int (&xcol)[3],
-                                              const int (&xslot)[3], int npix, uint32_t *side) {
+// ---- the plan of a frame: row marks, straddling pixels, per-strip pixel maps -----------------
+// One workgroup per frame; the decoder's two grid axes are staged in LDS first (every box rule
+// below is a chain of grid look-ups, and from global memory each link is a round trip), the
+// row plan is built in LDS and written out once.
+//
+// Rows (walk_fuse_plan_kernel's rule, sat_fuse_kernels.h, plus the band condition): reduced row j
+// is the box of table rows (lo, hi]; a tile holds ONE snapshot and starts with the table row
+// above its band, so row j is emitted by the writer iff no processed neighbour snapshots
+// strictly inside (lo, hi), no earlier reduced row emits at the same table row, and all of
+// lo + 1 .. hi lie in one band.  Such rows get EMIT | j | height at hi and SNAP at lo; the others
+// are listed for the fix-up (one per band boundary at most, none where boxes are one row high).
+//
+// Columns, per strip of 256: a box one column wide that ends at column x (and begins in the same
+// strip) is recorded AT x -- the lane that holds column x has everything such a pixel needs in
+// registers -- wider boxes inside the strip are listed {hi : 8 | lo : 8 | reduced column : 16},
+// boxes that straddle two strips go to the side-row list like the strip walker's.
+constexpr uint32_t kNoPixel = 0xffffffffu;
+
+__global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, int src_w,
+                                                             int src_h) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t plds[];
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int nstrips = (src_w + kStripPx - 1) / kStripPx;
+  // LDS: the row plan, then the two grids as int16 (each rounded up to whole dwords)
+  uint32_t *lplan = plds;
+  int16_t *sgx = reinterpret_cast<int16_t *>(plds + wf.plan_stride);
+  int16_t *sgy = sgx + ((wf.out_w + 2) & ~1);
+  __shared__ uint32_t n_wide[kFixCols / 4], widest[kFixCols / 4];
+  __shared__ int count, nleft;
+  for (int i = t; i <= wf.out_w; i += 256) sgx[i] = wf.gx[i];
+  for (int j = t; j <= wf.out_h; j += 256) sgy[j] = wf.gy[j];
+  for (int y = t; y < wf.plan_stride; y += 256) lplan[y] = 0;
+  for (int s = t; s < nstrips; s += 256) {
+    n_wide[s] = 0;
+    widest[s] = 1;
+  }
+  if (t == 0) count = nleft = 0;
+  uint32_t *ent = wf.ent + (size_t)f * nstrips * kBandEntStride;
+  for (int k = t; k < nstrips * 256; k += 256)
+    ent[(size_t)(k >> 8) * kBandEntStride + kBandEntUnit + (k & 255)] = kNoPixel;
+  __syncthreads();
+
+  uint32_t *sp = wf.spix + (size_t)f * kSpixWords;
+  const int cyp = wf.cyp[f], cxp = wf.cxp[f];
+  for (int j = t; j < wf.out_h; j += 256) {
+    const f360::AxisBox b = f360::sample_axis(cyp, sgy[j + 1], sgy[j], src_h, false);
+    if (!b.ok) continue;
+    bool fused = (b.lo + 1) / wf.band_rows == b.hi / wf.band_rows;
+    for (int d = 1; d <= 3; ++d) {
+      if (j + d < wf.out_h) {
+        const f360::AxisBox n = f360::sample_axis(cyp, sgy[j + d + 1], sgy[j + d], src_h, false);
+        if (n.ok && n.lo > b.lo && n.lo < b.hi) fused = false;
+      }
+      if (j - d >= 0) {
+        const f360::AxisBox p = f360::sample_axis(cyp, sgy[j - d + 1], sgy[j - d], src_h, false);
+        if (p.ok && p.hi == b.hi) fused = false;
+      }
+    }
+    if (fused) {
+      atomicOr(&lplan[b.hi], kFuseEmit | (uint32_t)j | ((uint32_t)(b.hi - b.lo) << 16));
+      atomicOr(&lplan[b.lo], kFuseSnap);
+    } else {
+      const int k = atomicAdd(&nleft, 1);
+      if (k < wf.lrows_max) sp[kSpixLrows + 1 + k] = (uint32_t)j;
+    }
+  }
+  // columns: reduced columns in chunks of 256, ascending, a barrier between chunks -- a strip's
+  // list of wide boxes then ascends from chunk to chunk whatever order one chunk's atomics
+  // come in, so a round of 64 of them stores to few lines
+  for (int i0 = 0; i0 < wf.out_w; i0 += 256) {
+    const int i = i0 + t;
+    if (i < wf.out_w) {
+      const f360::AxisBox bx = f360::sample_axis(cxp, sgx[i + 1], sgx[i], src_w, true);
+      if (bx.ok) {
+        const int s = bx.hi >> 8;
+        uint32_t *e = ent + (size_t)s * kBandEntStride;
+        if ((bx.lo >> 8) != s) {  // straddles two strips
+          const int k = atomicAdd(&count, 1);
+          if (k < kFixCols) {
+            sp[1 + 3 * k] = (uint32_t)i;
+            sp[2 + 3 * k] = (uint32_t)bx.hi;
+            sp[3 + 3 * k] = (uint32_t)bx.lo;
+          }
+        } else if (bx.hi - bx.lo == 1 &&
+                   atomicCAS(&e[kBandEntUnit + (bx.hi & 255)], kNoPixel, (uint32_t)i * 4u) == kNoPixel) {
+          // (recorded at its column; a second one-column box ending at the same column -- two
+          // wrap classes meeting -- goes to the list below)
+        } else {
+          const uint32_t k = atomicAdd(&n_wide[s], 1u);
+          atomicMax(&widest[s], (uint32_t)(bx.hi - bx.lo));
+          if (k < (uint32_t)kFuseEntries)  // (a strip cannot hold more: <= 256 per wrap class)
+            e[kBandEntWide + k] =
+                (uint32_t)(bx.hi & 255) | ((uint32_t)(bx.lo & 255) << 8) | ((uint32_t)i << 16);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  uint32_t *plan = wf.rowplan + (size_t)f * wf.plan_stride;
+  for (int y = t; y < wf.plan_stride; y += 256) plan[y] = lplan[y];
+  for (int s = t; s < nstrips; s += 256) {
+    uint32_t *e = ent + (size_t)s * kBandEntStride;
+    e[0] = min(n_wide[s], (uint32_t)kFuseEntries);
+    e[1] = widest[s];
+  }
+  if (t == 0) {
+    sp[0] = (uint32_t)count;
+    sp[kSpixLrows] = (uint32_t)nleft;
+  }
+}
+
+// The wide boxes of one emitted row: one per lane and round, gathered from the wave's D row in
+// LDS (`dlds`, 12 bytes per column, written by the caller just before).  Round 0's entries live
+// in registers (`e0`: {hi * 12 | lo * 12 << 12 | width << 24, reduced column * 4}); a strip
+// with more than 64 wide boxes reads the further rounds' entries from its list in LDS (`elds`,
+// 8 bytes per box, same packing).  Every asm statement ends with its own wait: nothing is in
+// flight between two of them, so the compiler may move or copy their results as it likes.
+__device__ __forceinline__ void band_emit_wide(uint32_t pr, uint8_t *orow, uint32_t dlds,
+                                               uint32_t elds, int lane, int n_ent, u32x2 e0,
+                                               uint32_t max_dxw) {
   const uint32_t dy = (pr >> 16) & 0x3ffu;
-  const bool one_row = dy == 1u;
-  uint8_t *orow = dst + (size_t)(pr & 0xffffu) * wf.dst_linesize;
   const bool quick = dy * max_dxw <= 2048u;  // the float quotient is exact (tests/test_fuse_div.py)
   const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
-  // Every asm statement below ends with its own wait: nothing is in flight between two of them,
-  // so the compiler may move or copy their results as it likes.  A round's statement issues the
-  // NEXT round's entry read together with this round's gathers -- one LDS round trip per round.
-  u32x2 es;
-  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-               : "=v"(es)
-               : "v"(elds + (uint32_t)lane * 8u)
-               : "memory");
-  for (int e0 = 0; e0 < n_ent; e0 += 64) {
+  u32x2 es = e0;
+  for (int b0 = 0; b0 < n_ent; b0 += 64) {
     const uint32_t eoff = es.x, estore = es.y;
-    const bool valid = e0 + lane < n_ent;
-    // (the list area is one round longer than 768 entries: the read past the last round is legal)
-    const uint32_t next = elds + (uint32_t)(e0 + 64 + lane) * 8u;
-    if (one_row && e0 + 64 <= n_unit) {  // the fovea: a reduced pixel IS a source pixel
-      uint32_t p;
-      asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(es), "=&v"(p)
-                   : "v"(next), "v"(plds + (estore >> 22) * 4u)
-                   : "memory");
-      asm volatile(  // R, G from the low half, B from byte 2
-          "global_store_short %0, %1, %2 nt\n\t"
-          "global_store_byte_d16_hi %0, %1, %2 offset:2 nt" ::"v"(estore & 0x3fffffu),
-          "v"(p), "s"(orow)
-          : "memory");
-      continue;
-    }
+    const bool valid = b0 + lane < n_ent;
     u32x2 h01, l01;
     uint32_t h2, l2;
-    asm volatile(
-        "ds_read_b64 %0, %5\n\t"
-        "ds_read2_b32 %1, %6 offset1:1\n\t"
-        "ds_read_b32 %2, %6 offset:8\n\t"
-        "ds_read2_b32 %3, %7 offset1:1\n\t"
-        "ds_read_b32 %4, %7 offset:8\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(es), "=&v"(h01), "=&v"(h2), "=&v"(l01), "=&v"(l2)
-        : "v"(next), "v"(dlds + (eoff & 0xfffu)), "v"(dlds + ((eoff >> 12) & 0xfffu))
-        : "memory");
+    if (b0 + 64 < n_ent) {  // (wave-uniform) the next round's entry along with this round's gathers
+      asm volatile(
+          "ds_read_b64 %0, %5\n\t"
+          "ds_read2_b32 %1, %6 offset1:1\n\t"
+          "ds_read_b32 %2, %6 offset:8\n\t"
+          "ds_read2_b32 %3, %7 offset1:1\n\t"
+          "ds_read_b32 %4, %7 offset:8\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(es), "=&v"(h01), "=&v"(h2), "=&v"(l01), "=&v"(l2)
+          : "v"(elds + (uint32_t)(b0 + 64 + lane) * 8u), "v"(dlds + (eoff & 0xfffu)),
+            "v"(dlds + ((eoff >> 12) & 0xfffu))
+          : "memory");
+    } else {
+      asm volatile(
+          "ds_read2_b32 %0, %4 offset1:1\n\t"
+          "ds_read_b32 %1, %4 offset:8\n\t"
+          "ds_read2_b32 %2, %5 offset1:1\n\t"
+          "ds_read_b32 %3, %5 offset:8\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(h01), "=&v"(h2), "=&v"(l01), "=&v"(l2)
+          : "v"(dlds + (eoff & 0xfffu)), "v"(dlds + ((eoff >> 12) & 0xfffu))
+          : "memory");
+    }
     const uint3 n = make_uint3(h01.x - l01.x, h01.y - l01.y, h2 - l2);
     const uint32_t dxw = eoff >> 24;
     if (quick) {
@@ -95,29 +194,11 @@ __device__ __forceinline__ void band_emit_row(uint32_t pr, const WalkFuse &wf, u
       const uint32_t qx = (uint32_t)__builtin_fmaf((float)n.x, inv, 0x1p-12f);
       const uint32_t qy = (uint32_t)__builtin_fmaf((float)n.y, inv, 0x1p-12f);
       const uint32_t qz = (uint32_t)__builtin_fmaf((float)n.z, inv, 0x1p-12f);
-      if (valid) fuse_store_rgb(orow, estore & 0x3fffffu, qx | (qy << 8), qz);
+      if (valid) fuse_store_rgb(orow, estore, qx | (qy << 8), qz);
     } else {
       const uint3 q = fuse_div3(n, dxw * dy);
-      if (valid) fuse_store_rgb(orow, estore & 0x3fffffu, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
+      if (valid) fuse_store_rgb(orow, estore, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
     }
-  }
-  if (exports) {  // this strip's columns of the boxes that straddle two strips
-    u32x2 x01[3];
-    uint32_t x2[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\t"
-                   "s_waitcnt lgkmcnt(0)"
-                   : "=&v"(x01[k]), "=&v"(x2[k])
-                   : "v"(dlds + (uint32_t)xcol[k] * 12u)
-                   : "memory");
-    uint32_t *srow = side + (size_t)(pr & 0xffffu) * npix * 6;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (xslot[k] >= 0)
-        asm volatile("global_store_dwordx3 %0, %1, %2" ::"v"((uint32_t)xslot[k] * 12u),
-                     "v"(u32x3v{x01[k].x, x01[k].y, x2[k]}), "s"(srow)
-                     : "memory");
   }
 }
 
@@ -128,9 +209,9 @@ template <int SRC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
     const EncodeArgs a, const EncodeBatch eb, const WalkFuse wf, int frame0) {
   static_assert(SRC == kSrcRgb0, "the band writer's one pass takes RGB0 frames");
-  // per wave: 3 KiB store staging / D row, 1 KiB source-pixel row, 6 KiB pixel list (+ one
-  // round of slack: the emit loop requests the entry of the round after the last)
-  constexpr int kWaveDwords = 4 * kStripPx + 2 * (kFuseEntries + 64);
+  // per wave: 3 KiB store staging / D row, then the strip's list of wide boxes past the first
+  // round (8 bytes each; 6 KiB, hardly ever used)
+  constexpr int kWaveDwords = 3 * kStripPx + 2 * kFuseEntries;
   __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock * kWaveDwords];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -143,8 +224,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
   const int sb = band / a.sb_bands;
   const int f = frame0 + (a.nbatch != 0 ? (int)blockIdx.y : 0);
   const uint32_t mine = (uint32_t)reinterpret_cast<uintptr_t>(stage) + wave * kWaveDwords * 4;
-  const uint32_t plds = mine + 3 * kStripPx * 4;
-  const uint32_t elds = plds + kStripPx * 4;
+  const uint32_t elds = mine + 3 * kStripPx * 4;
 
   const int y_end = min((band + 1) * a.band_rows, a.height);
   const uint32_t *rc = a.rowcarry + fr.ws + (size_t)strip * a.height * 3;
@@ -163,18 +243,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
   load_batch(buf_a, carry_a, y_begin);
   load_batch(buf_b, carry_b, y_begin + kRowUnroll);
 
-  // --- the strip's reduced pixels (plan kernel's list) and its straddling columns -----------
+  // --- the strip's reduced pixels (band_fuse_plan_kernel) and its straddling columns --------
   const uint32_t *ent = wf.ent + ((size_t)f * a.nstrips + strip) * kBandEntStride;
   const int n_ent = (int)ent[0];
   const uint32_t max_dxw = ent[1];
-  const int n_unit = (int)ent[2];
-  for (int e0 = 0; e0 < n_ent; e0 += 64) {
-    const int e = e0 + lane;
-    const uint32_t en = e < n_ent ? ent[kBandEntHead + e] : 0x00000100u;  // (hi 0, lo 1: harmless)
+  // this lane's four columns: where the one-column box that ends there goes (byte offset in the
+  // reduced row), ~0 if none
+  uint32_t ux[4];
+  {
+    const uint4 u = *reinterpret_cast<const uint4 *>(ent + kBandEntUnit + lane * 4);
+    ux[0] = u.x, ux[1] = u.y, ux[2] = u.z, ux[3] = u.w;
+  }
+  const bool any_unit = __any((ux[0] & ux[1] & ux[2] & ux[3]) != kNoPixel);
+  u32x2 e0;
+  {
+    const uint32_t en = lane < n_ent ? ent[kBandEntWide + lane] : 0x00000100u;  // (hi 0, lo 1: harmless)
     const uint32_t hi = en & 255u, lo = (en >> 8) & 255u;
-    const uint32_t dxw = e < n_ent ? hi - lo : 1u;
-    lds_write_b64(elds + (uint32_t)e * 8u, (hi * 12u) | ((lo * 12u) << 12) | (dxw << 24),
-                  ((en >> 16) * 4u) | (hi << 22));
+    e0.x = (hi * 12u) | ((lo * 12u) << 12) | ((lane < n_ent ? hi - lo : 1u) << 24);
+    e0.y = (en >> 16) * 4u;
+  }
+  for (int b0 = 64; b0 < n_ent; b0 += 64) {  // (more than one round of wide boxes: rare)
+    const int e = b0 + lane;
+    const uint32_t en = e < n_ent ? ent[kBandEntWide + e] : 0x00000100u;
+    const uint32_t hi = en & 255u, lo = (en >> 8) & 255u;
+    lds_write_b64(elds + (uint32_t)e * 8u,
+                  (hi * 12u) | ((lo * 12u) << 12) | ((e < n_ent ? hi - lo : 1u) << 24),
+                  (en >> 16) * 4u);
   }
   const uint32_t *sp = wf.spix + (size_t)f * kSpixWords;
   int npix = (int)sp[0];
@@ -197,6 +291,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
     }
   }
   const bool exports = __any(xslot[0] >= 0) || __any(xslot[1] >= 0) || __any(xslot[2] >= 0);
+  const bool needs_d = n_ent > 0 || exports;  // (else the D row never goes through LDS)
   uint8_t *dst = wf.dst[f];
   uint32_t *side = wf.side + (size_t)f * wf.side_stride;
 
@@ -281,18 +376,75 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
       }
       const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)carry, 32 + r);  // plan[y + r]
       if (pr & kFuseEmit) {
-        // D = this row - snapshot into the staging slice (its reads have returned), the row's
-        // pixels beside it where the fovea's short cut can apply
-        lds_write_b128(mine + lane * 48, u32x4{acc[0] - snap[0], acc[1] - snap[1],
-                                                acc[2] - snap[2], acc[3] - snap[3]});
-        lds_write_b128(mine + lane * 48 + 16, u32x4{acc[4] - snap[4], acc[5] - snap[5],
-                                                     acc[6] - snap[6], acc[7] - snap[7]});
-        lds_write_b128(mine + lane * 48 + 32, u32x4{acc[8] - snap[8], acc[9] - snap[9],
-                                                     acc[10] - snap[10], acc[11] - snap[11]});
-        if (((pr >> 16) & 0x3ffu) == 1u)
-          lds_write_b128(plds + lane * 16, u32x4{px[0], px[1], px[2], px[3]});
-        band_emit_row(pr, wf, dst, mine, plds, elds, lane, n_ent, n_unit, max_dxw, exports, xcol,
-                      xslot, npix, side);
+        const uint32_t dy = (pr >> 16) & 0x3ffu;
+        uint8_t *orow = dst + (size_t)(pr & 0xffffu) * wf.dst_linesize;
+        // (1) boxes one column wide, from registers: a lane has both of their columns, or takes
+        // the left one from its neighbour (the first column of a strip never ends such a box:
+        // its left column lies in the other strip)
+        if (any_unit) {
+          if (dy == 1u) {  // the fovea: a reduced pixel IS a source pixel
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (ux[k] != kNoPixel)
+                asm volatile(
+                    "global_store_short %0, %1, %2 nt\n\t"
+                    "global_store_byte_d16_hi %0, %1, %2 offset:2 nt" ::"v"(ux[k]),
+                    "v"(px[k]), "s"(orow)
+                    : "memory");
+          } else {
+            // D = row - snapshot; box = D[x] - D[x - 1]; dy <= band height: the float quotient
+            // is exact (tests/test_fuse_div.py)
+            const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
+            uint32_t left[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)  // D of the lane to the left's fourth column
+              left[ch] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(acc[9 + ch] - snap[9 + ch]),
+                                                               0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              uint32_t q[3];
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) {
+                const uint32_t d = acc[3 * k + ch] - snap[3 * k + ch];
+                const uint32_t n = d - left[ch];
+                left[ch] = d;
+                q[ch] = (uint32_t)__builtin_fmaf((float)n, inv_dy, 0x1p-12f);
+              }
+              if (ux[k] != kNoPixel) fuse_store_rgb(orow, ux[k], q[0] | (q[1] << 8), q[2]);
+            }
+          }
+        }
+        // (2) wider boxes and the columns of boxes that straddle two strips: D row through the
+        // staging slice (its reads have returned)
+        if (needs_d) {
+          lds_write_b128(mine + lane * 48, u32x4{acc[0] - snap[0], acc[1] - snap[1],
+                                                  acc[2] - snap[2], acc[3] - snap[3]});
+          lds_write_b128(mine + lane * 48 + 16, u32x4{acc[4] - snap[4], acc[5] - snap[5],
+                                                       acc[6] - snap[6], acc[7] - snap[7]});
+          lds_write_b128(mine + lane * 48 + 32, u32x4{acc[8] - snap[8], acc[9] - snap[9],
+                                                       acc[10] - snap[10], acc[11] - snap[11]});
+          if (n_ent > 0) band_emit_wide(pr, orow, mine, elds, lane, n_ent, e0, max_dxw);
+          if (exports) {
+            u32x2 x01[3];
+            uint32_t x2[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\t"
+                           "s_waitcnt lgkmcnt(0)"
+                           : "=&v"(x01[k]), "=&v"(x2[k])
+                           : "v"(mine + (uint32_t)xcol[k] * 12u)
+                           : "memory");
+            uint32_t *srow = side + (size_t)(pr & 0xffffu) * npix * 6;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (xslot[k] >= 0)
+                asm volatile("global_store_dwordx3 %0, %1, %2" ::"v"((uint32_t)xslot[k] * 12u),
+                             "v"(u32x3v{x01[k].x, x01[k].y, x2[k]}), "s"(srow)
+                             : "memory");
+          } else {
+            // (the gathers above ended with their own wait; the next row's staging may follow)
+          }
+        }
       }
       if (pr & kFuseSnap) {
 #pragma unroll
@@ -320,13 +472,18 @@ void f360::sat::launch_write_fuse(f360_ctx *ctx, const EncodeArgs &a, const Enco
 
 // Whether f360_satdec_encode_sample_frames can take the band writer's one pass for this call
 // ("fuse.band"; the caller has already found the strip walker's form not applicable).
+static size_t band_plan_lds_bytes(int height, int out_w, int out_h) {
+  const int plan_stride = ((height + kRowUnroll - 1) / kRowUnroll) * kRowUnroll;
+  return (size_t)plan_stride * 4 + (size_t)((out_w + 2) & ~1) * 2 + (size_t)((out_h + 2) & ~1) * 2;
+}
 bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int height,
                                           int linesize, int out_w, int out_h, int dst_linesize) {
   return ctx->opt_fuse_band != 0 && linesize / width == 4 && linesize % 16 == 0 &&
          width % 4 == 0 && width <= f360::kMaxDim &&
          (size_t)width * height * 3 < ((size_t)1 << 31) && out_w < 65536 && out_h < 65536 &&
          (width + kStripPx - 1) / kStripPx <= kFixCols / 4 && dst_linesize % 4 == 0 &&
-         dst_linesize >= 4 * out_w;
+         dst_linesize >= 4 * out_w &&
+         band_plan_lds_bytes(height, out_w, out_h) <= 60 * 1024;  // the plan kernel's LDS
 }
 
 // f360_satdec_encode_sample_frames on the three-kernel encoder: one plan launch and one fix-up
@@ -339,15 +496,23 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
   const int nstrips = (width + kStripPx - 1) / kStripPx;
   const int plan_stride = ((height + kRowUnroll - 1) / kRowUnroll) * kRowUnroll;
   const int pmax = (ctx->opt_fuse_force & 1) ? 1 : std::max(1, std::min(3 * (nstrips - 1), kFixCols));
-  const size_t side_stride = (size_t)fuse.out_h * pmax * 6;  // dwords per frame
+  const size_t side_stride = ((size_t)fuse.out_h * pmax * 6 + 3) & ~(size_t)3;  // dwords per frame
   const size_t frame_bytes = (size_t)linesize * height;
   const int per_launch = (int)std::min<size_t>(
       std::max<size_t>(((size_t)std::max(ctx->opt_batch_mb, 1) << 20) / frame_bytes, 1),
       (size_t)kEncBatch);
+  // (the band height is the encoder plan's: make sure it exists before the plan kernel runs)
+  int st = f360_sat_encode_prepare(ctx, width, height);
+  if (st != F360_OK) return st;
+  const int band_rows = p.band_rows, nbands = (height + band_rows - 1) / band_rows;
+  // reduced rows the plan cannot mark: one per band boundary at most, plus the clamped edge rows
+  const int lrows_max = (ctx->opt_fuse_force & 2) ? 0 : std::min(kFixLrowsBand, nbands + 4);
   for (int c0 = 0; c0 < count; c0 += kWalkFrames) {
     const int n = std::min(count - c0, kWalkFrames);
-    const size_t words = (size_t)n * plan_stride + (size_t)n * kSpixWords + (size_t)n * side_stride +
-                         (size_t)n * nstrips * kBandEntStride;
+    // one buffer: pixel maps | row plans | straddling pixels | side rows (16-byte aligned parts)
+    const size_t ent_words = (size_t)n * nstrips * kBandEntStride;
+    const size_t words = ent_words + (size_t)n * plan_stride + (size_t)n * kSpixWords +
+                         (size_t)n * side_stride;
     if (words * 4 > p.walk_plan.bytes) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       F360_HIP_TRY(hipStreamIsCapturing(ctx->stream, &cap));
@@ -356,7 +521,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
                    "allocated but the stream is being captured; run the same call once before "
                    "the capture", words * 4);
       if (p.walk_plan.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
-      int st = p.walk_plan.reserve(words * 4);
+      st = p.walk_plan.reserve(words * 4);
       if (st != F360_OK) return st;
     }
     f360::SatBandFuse bf;
@@ -371,7 +536,8 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
     }
     wf.gx = fuse.gx;
     wf.gy = fuse.gy;
-    wf.rowplan = p.walk_plan.as<uint32_t>();
+    wf.ent = p.walk_plan.as<uint32_t>();
+    wf.rowplan = wf.ent + ent_words;
     wf.plan_stride = plan_stride;
     wf.out_w = fuse.out_w;
     wf.out_h = fuse.out_h;
@@ -380,16 +546,13 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
     wf.side = wf.spix + (size_t)n * kSpixWords;
     wf.pmax = pmax;
     wf.side_stride = side_stride;
-    wf.lrows_max = (ctx->opt_fuse_force & 2) ? 0 : kFixLrowsBand;
-    wf.ent = wf.side + (size_t)n * side_stride;
-    // (the band height is the encoder plan's: make sure it exists before the plan kernel runs)
-    int st = f360_sat_encode_prepare(ctx, width, height);
-    if (st != F360_OK) return st;
-    wf.band_rows = p.band_rows;
+    wf.lrows_max = lrows_max;
+    wf.band_rows = band_rows;
     {
       f360::KernelSpan span(ctx, f360::kWalkFusePlan, prof, n);
-      hipLaunchKernelGGL(walk_fuse_plan_kernel<true>, dim3(n), dim3(256), 0, ctx->stream, wf.gy,
-                         wf.out_h, width, height, wf.rowplan, plan_stride, wf);
+      hipLaunchKernelGGL(band_fuse_plan_kernel, dim3(n), dim3(256),
+                         band_plan_lds_bytes(height, fuse.out_w, fuse.out_h), ctx->stream, wf,
+                         width, height);
     }
     for (int k0 = 0; k0 < n; k0 += per_launch) {
       const int m = std::min(n - k0, per_launch);
@@ -397,7 +560,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
       st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr, nullptr,
                                  m, sats + c0 + k0, srcs + c0 + k0, prof ? 1 : 0, nullptr, &bf);
       if (st != F360_OK) return st;
-      if (ctx->enc.band_rows != wf.band_rows) {  // (cannot happen: same geometry, same options)
+      if (ctx->enc.band_rows != band_rows) {  // (cannot happen: same geometry, same options)
         f360::set_error("f360_satdec_encode_sample_frames: the encoder plan changed under the call");
         return F360_ERR_INVALID_ARG;
       }
@@ -406,7 +569,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
       f360::KernelSpan span(ctx, f360::kWalkFuseFix, prof, n);
       hipLaunchKernelGGL(walk_fuse_fix_kernel<0>,
                          dim3((wf.out_h * pmax + 255) / 256 +
-                                  kFixLrowsBand * ((wf.out_w + 255) / 256), n),
+                                  std::max(lrows_max, 1) * ((wf.out_w + 255) / 256), n),
                          dim3(256), 0, ctx->stream, wb, wf, width, height, linesize, -1,
                          f360::YuvPlanes{nullptr, nullptr, nullptr, 0, 0, 0}, f360::YuvConsts{});
     }

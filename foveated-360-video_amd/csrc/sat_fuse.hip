@@ -62,7 +62,7 @@ int f360::sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats
     wf.ent = nullptr;
     {
       f360::KernelSpan span(ctx, f360::kWalkFusePlan, prof, n);
-      hipLaunchKernelGGL(walk_fuse_plan_kernel<false>, dim3(n), dim3(256), 0, ctx->stream, wf.gy,
+      hipLaunchKernelGGL(walk_fuse_plan_kernel<0>, dim3(n), dim3(256), 0, ctx->stream, wf.gy,
                          wf.out_h, width, height, wf.rowplan, ws.plan_stride, wf);
     }
     {

@@ -59,8 +59,13 @@ constexpr int kSpixWords = 1024;  // 1 + 3 * kFixCols, rounded up; the tail: red
 constexpr int kSpixLrows = 800;   // cannot emit ({count, rows}), at most WalkFuse::lrows_max listed
 constexpr int kFixLrowsWalk = 16;   // strip walker: rows clamped onto the frame's edges, 0 or 1 at 8K
 constexpr int kFixLrowsBand = 200;  // band writer: also one box per band boundary at most
-constexpr int kBandEntHead = 64;    // words of a strip's pixel list before its entries
-constexpr int kBandEntStride = kBandEntHead + 3 * 256;
+// band writer: per (frame, strip) {head: wide boxes listed, widest box, ...} | for every column
+// the reduced pixel of the one-column box that ends there (byte offset in the reduced row, or
+// ~0) | the wide boxes {hi column : 8 | lo column : 8 | reduced column : 16}
+constexpr int kBandEntHead = 64;
+constexpr int kBandEntUnit = kBandEntHead;           // word offset of the per-column map
+constexpr int kBandEntWide = kBandEntHead + 256;     // word offset of the list of wide boxes
+constexpr int kBandEntStride = kBandEntWide + 3 * 256;
 struct WalkNoFuse {};
 }  // namespace sat
 // what sat_encode_impl hands to the table writer's launch in one-pass form (sat_band_fuse.hip)

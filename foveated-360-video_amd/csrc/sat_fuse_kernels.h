@@ -1,7 +1,6 @@
-// sat_fuse_kernels.h -- the two small kernels around a one-pass encode + sample launch: the row
-// plan before it and the fix-up after it.  Templates, so that both one-pass forms instantiate
-// them: the strip walker's (sat_fuse.hip, BAND false) and the band writer's (sat_band_fuse.hip,
-// BAND true: an owner holds one band of a strip, not the whole strip).
+// sat_fuse_kernels.h -- the two small kernels around a one-pass encode + sample launch: the
+// strip walker's row plan before it (the band writer has its own, sat_band_fuse.hip) and the
+// fix-up after it, which both one-pass forms share.
 #pragma once
 
 #include "sat_walk.h"
@@ -20,17 +19,7 @@ namespace sat {
 //     frame's last table row).
 // Such rows get their marks -- EMIT | j | height at hi, SNAP at lo -- and every other processed
 // row is left to walk_fuse_fix_kernel, which recognises it by the missing mark.
-//
-// BAND (the band writer's one pass, sat_band_fuse.hip): an owner holds the rows of ONE band of
-// `wf.band_rows` rows and starts with the table row above the band as its snapshot (the writer's
-// prologue computes exactly that row), so a reduced row is emitted iff, in addition, all of its
-// table rows lo + 1 .. hi lie in one band; a box that crosses a band boundary goes to the fix-up
-// (one per boundary at most, none where boxes are one row high).  The plan kernel then also
-// lists, per strip, the reduced pixels whose box lies inside the strip -- what a strip walker's
-// helper works out for itself once per 3840 rows a band owner would work out once per 64 --
-// {hi column : 8 | lo column : 8 | reduced column : 16}, boxes one column wide first
-// (wf.ent[frame][strip]: {count, widest box, -, ...}, entries from word kBandEntHead on).
-template <bool BAND>
+template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__restrict__ gy,
                                                              int out_h, int src_w, int src_h,
                                                              uint32_t *__restrict__ rowplan,
@@ -57,7 +46,6 @@ __global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__re
         if (p.ok && p.hi == b.hi) fused = false;
       }
     }
-    if (BAND && (b.lo + 1) / wf.band_rows != b.hi / wf.band_rows) fused = false;
     if (fused) {
       atomicOr(&plan[b.hi], kFuseEmit | (uint32_t)j | ((uint32_t)(b.hi - b.lo) << 16));
       atomicOr(&plan[b.lo], kFuseSnap);
@@ -84,50 +72,6 @@ __global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__re
   if (threadIdx.x == 0) {
     sp[0] = (uint32_t)count;
     sp[kSpixLrows] = (uint32_t)nleft;
-  }
-  if constexpr (BAND) {
-    // Per strip: the boxes one column wide first (their count comes from a first pass), then the
-    // wider ones.  The second pass takes the reduced columns in chunks of 256 in ascending order
-    // with a barrier between chunks, so a strip's list ascends from chunk to chunk (a round of
-    // 64 entries stores to few lines) whatever order the atomics of one chunk come in.
-    __shared__ uint32_t n_unit[kFixCols / 4], at_unit[kFixCols / 4], at_wide[kFixCols / 4],
-        widest[kFixCols / 4];
-    const int nstrips = (src_w + kStripPx - 1) / kStripPx;
-    for (int s = threadIdx.x; s < nstrips; s += 256) {
-      n_unit[s] = at_unit[s] = at_wide[s] = 0;
-      widest[s] = 1;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < wf.out_w; i += 256) {
-      const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[i + 1], wf.gx[i], src_w, true);
-      if (bx.ok && (bx.hi >> 8) == (bx.lo >> 8)) {
-        if (bx.hi - bx.lo == 1) atomicAdd(&n_unit[bx.hi >> 8], 1u);
-        else atomicMax(&widest[bx.hi >> 8], (uint32_t)(bx.hi - bx.lo));
-      }
-    }
-    __syncthreads();
-    uint32_t *ent = wf.ent + (size_t)blockIdx.x * nstrips * kBandEntStride;
-    for (int i0 = 0; i0 < wf.out_w; i0 += 256) {
-      const int i = i0 + (int)threadIdx.x;
-      if (i < wf.out_w) {
-        const f360::AxisBox bx = f360::sample_axis(cxp, wf.gx[i + 1], wf.gx[i], src_w, true);
-        if (bx.ok && (bx.hi >> 8) == (bx.lo >> 8)) {
-          const int s = bx.hi >> 8;
-          const uint32_t k = bx.hi - bx.lo == 1 ? atomicAdd(&at_unit[s], 1u)
-                                                : n_unit[s] + atomicAdd(&at_wide[s], 1u);
-          if (k < (uint32_t)kFuseEntries)  // (a strip cannot own more: <= 256 per wrap class)
-            ent[(size_t)s * kBandEntStride + kBandEntHead + k] =
-                (uint32_t)(bx.hi & 255) | ((uint32_t)(bx.lo & 255) << 8) | ((uint32_t)i << 16);
-        }
-      }
-      __syncthreads();
-    }
-    for (int s = threadIdx.x; s < nstrips; s += 256) {
-      uint32_t *e = ent + (size_t)s * kBandEntStride;
-      e[0] = min(n_unit[s] + at_wide[s], (uint32_t)kFuseEntries);
-      e[1] = widest[s];
-      e[2] = n_unit[s];
-    }
   }
 }
 

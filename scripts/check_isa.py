@@ -120,6 +120,29 @@ def main():
                                 any(t.startswith("s_waitcnt vmcnt(0)") for t in lt):
                             perf.append(f"{name}: s_waitcnt vmcnt(0) inside a storing loop "
                                         f"({len(lt)} instructions)")
+                # the band writer's one pass (sat_band_fuse.hip): the table writer's rules -- nt
+                # table stores, no drain inside a storing loop, no scratch -- and nt pixel stores
+                if "sat_write_fuse_kernel" in name:
+                    seen.add("one-pass writer")
+                    if any(t.startswith(("scratch_", "s_swappc")) for t in texts):
+                        perf.append(f"{name}: scratch memory or a call in the one-pass writer")
+                    stores = [t for t in texts if t.startswith("global_store_dwordx4")]
+                    if len(stores) < 24 or any(" nt" not in t for t in stores):
+                        perf.append(f"{name}: a table store lost its nt bit")
+                    if any(" nt" not in t for t in texts if t.startswith(("global_store_short", "global_store_byte"))):
+                        perf.append(f"{name}: a pixel store lost its nt bit")
+                    # the row loop = the smallest loop that holds a double batch's table stores
+                    # (cold blocks placed behind the loop jump back into the prologue: such a
+                    # "loop" spans the whole kernel and is not the one meant)
+                    cand = [[t for _, t, _ in lp] for lp in all_loops(ins)]
+                    cand = [lt for lt in cand if sum(t.startswith("global_store_dwordx4") for t in lt) >= 24]
+                    if not cand:
+                        perf.append(f"{name}: no row loop (24 table stores) found")
+                    elif any(t.startswith("s_waitcnt vmcnt(0)") for t in min(cand, key=len)):
+                        perf.append(f"{name}: s_waitcnt vmcnt(0) inside the row loop "
+                                    f"({len(min(cand, key=len))} instructions)")
+                    if not any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in texts):
+                        perf.append(f"{name}: no counted vmcnt wait left")
                 if re.search(r"sat_reduce_kernelILi[123]EE", name):
                     seen.add("reducer")
                     # the steady-state loop: a batch of >= 8 row loads, waits that count the
@@ -215,7 +238,7 @@ def main():
                         perf.append(f"{name}: pixel stores lost their nt bit")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for k in ("writer", "reducer", "streamer", "batch streamer", "one-pass walker"):
+    for k in ("writer", "reducer", "streamer", "batch streamer", "one-pass walker", "one-pass writer"):
         if k not in seen:
             perf.append(f"no {k} kernel found in {lib}")
     # the library always exports f360_sat_encode_batch: without a recognised strip walker the

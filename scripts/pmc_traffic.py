@@ -41,7 +41,8 @@ def means(paths, counter):
                 continue
             # keep the template arguments: the benchmark's after-run variants launch other
             # instantiations of the same kernels (emit mode, planar sources)
-            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+            name = (row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("f360::sat::", "")
+                    .split("(")[0].replace("void ", ""))
             acc.setdefault(name.strip(), []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
