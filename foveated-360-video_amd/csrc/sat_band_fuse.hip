@@ -53,30 +53,49 @@ namespace {
 // boxes that straddle two strips go to the side-row list like the strip walker's.
 constexpr uint32_t kNoPixel = 0xffffffffu;
 
+constexpr int kPlanPerThread = 20;  // grid entries a thread stages at once: axes up to 5120
+
 __global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, int src_w,
                                                              int src_h) {
   extern __shared__ __attribute__((aligned(16))) uint32_t plds[];
   const int f = blockIdx.x, t = threadIdx.x;
   const int nstrips = (src_w + kStripPx - 1) / kStripPx;
-  // LDS: the row plan, then the two grids as int16 (each rounded up to whole dwords)
+  // LDS: the row plan | per column of every strip, the one-column box that ends there | the two
+  // grids as int16 (each rounded up to whole dwords)
   uint32_t *lplan = plds;
-  int16_t *sgx = reinterpret_cast<int16_t *>(plds + wf.plan_stride);
+  uint32_t *lunit = lplan + wf.plan_stride;
+  int16_t *sgx = reinterpret_cast<int16_t *>(lunit + nstrips * 256);
   int16_t *sgy = sgx + ((wf.out_w + 2) & ~1);
   __shared__ uint32_t n_wide[kFixCols / 4], widest[kFixCols / 4];
   __shared__ int count, nleft;
-  for (int i = t; i <= wf.out_w; i += 256) sgx[i] = wf.gx[i];
-  for (int j = t; j <= wf.out_h; j += 256) sgy[j] = wf.gy[j];
+  {
+    // every grid load of a thread issued before the first is used: staged one after the other
+    // the two axes are 26 dependent round trips (a third of this kernel's 26 us when it was
+    // written that way)
+    int16_t vx[kPlanPerThread], vy[kPlanPerThread];
+#pragma unroll
+    for (int k = 0; k < kPlanPerThread; ++k) {
+      vx[k] = wf.gx[min(t + 256 * k, wf.out_w)];
+      vy[k] = wf.gy[min(t + 256 * k, wf.out_h)];
+    }
+#pragma unroll
+    for (int k = 0; k < kPlanPerThread; ++k) {
+      if (t + 256 * k <= wf.out_w) sgx[t + 256 * k] = vx[k];
+      if (t + 256 * k <= wf.out_h) sgy[t + 256 * k] = vy[k];
+    }
+    for (int i = t + 256 * kPlanPerThread; i <= wf.out_w; i += 256) sgx[i] = wf.gx[i];
+    for (int j = t + 256 * kPlanPerThread; j <= wf.out_h; j += 256) sgy[j] = wf.gy[j];
+  }
   for (int y = t; y < wf.plan_stride; y += 256) lplan[y] = 0;
+  for (int k = t; k < nstrips * 256; k += 256) lunit[k] = kNoPixel;
   for (int s = t; s < nstrips; s += 256) {
     n_wide[s] = 0;
     widest[s] = 1;
   }
   if (t == 0) count = nleft = 0;
-  uint32_t *ent = wf.ent + (size_t)f * nstrips * kBandEntStride;
-  for (int k = t; k < nstrips * 256; k += 256)
-    ent[(size_t)(k >> 8) * kBandEntStride + kBandEntUnit + (k & 255)] = kNoPixel;
   __syncthreads();
 
+  uint32_t *ent = wf.ent + (size_t)f * nstrips * kBandEntStride;
   uint32_t *sp = wf.spix + (size_t)f * kSpixWords;
   const int cyp = wf.cyp[f], cxp = wf.cxp[f];
   for (int j = t; j < wf.out_h; j += 256) {
@@ -103,14 +122,15 @@ __global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, 
   }
   // columns: reduced columns in chunks of 256, ascending, a barrier between chunks -- a strip's
   // list of wide boxes then ascends from chunk to chunk whatever order one chunk's atomics
-  // come in, so a round of 64 of them stores to few lines
+  // come in, so a round of 64 of them stores to few lines.  Nothing in the loop waits for
+  // global memory: the counters and the per-column map live in LDS, the list entries are
+  // stores nobody waits for.
   for (int i0 = 0; i0 < wf.out_w; i0 += 256) {
     const int i = i0 + t;
     if (i < wf.out_w) {
       const f360::AxisBox bx = f360::sample_axis(cxp, sgx[i + 1], sgx[i], src_w, true);
       if (bx.ok) {
         const int s = bx.hi >> 8;
-        uint32_t *e = ent + (size_t)s * kBandEntStride;
         if ((bx.lo >> 8) != s) {  // straddles two strips
           const int k = atomicAdd(&count, 1);
           if (k < kFixCols) {
@@ -118,15 +138,14 @@ __global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, 
             sp[2 + 3 * k] = (uint32_t)bx.hi;
             sp[3 + 3 * k] = (uint32_t)bx.lo;
           }
-        } else if (bx.hi - bx.lo == 1 &&
-                   atomicCAS(&e[kBandEntUnit + (bx.hi & 255)], kNoPixel, (uint32_t)i * 4u) == kNoPixel) {
+        } else if (bx.hi - bx.lo == 1 && atomicCAS(&lunit[bx.hi], kNoPixel, (uint32_t)i * 4u) == kNoPixel) {
           // (recorded at its column; a second one-column box ending at the same column -- two
           // wrap classes meeting -- goes to the list below)
         } else {
           const uint32_t k = atomicAdd(&n_wide[s], 1u);
           atomicMax(&widest[s], (uint32_t)(bx.hi - bx.lo));
           if (k < (uint32_t)kFuseEntries)  // (a strip cannot hold more: <= 256 per wrap class)
-            e[kBandEntWide + k] =
+            ent[(size_t)s * kBandEntStride + kBandEntWide + k] =
                 (uint32_t)(bx.hi & 255) | ((uint32_t)(bx.lo & 255) << 8) | ((uint32_t)i << 16);
         }
       }
@@ -135,6 +154,8 @@ __global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, 
   }
   uint32_t *plan = wf.rowplan + (size_t)f * wf.plan_stride;
   for (int y = t; y < wf.plan_stride; y += 256) plan[y] = lplan[y];
+  for (int k = t; k < nstrips * 256; k += 256)
+    ent[(size_t)(k >> 8) * kBandEntStride + kBandEntUnit + (k & 255)] = lunit[k];
   for (int s = t; s < nstrips; s += 256) {
     uint32_t *e = ent + (size_t)s * kBandEntStride;
     e[0] = min(n_wide[s], (uint32_t)kFuseEntries);
@@ -375,13 +396,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
           global_store_b128_uncounted_nt(row + base + off, v[q]);
       }
       const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)carry, 32 + r);  // plan[y + r]
-      if (pr & kFuseEmit) {
+      // (debug.ablate, timing experiments: 1024 no emit at all, 2048 no one-column boxes,
+      // 4096 no wide boxes / side rows)
+      if ((pr & kFuseEmit) && !(a.ablate & 1024)) {
         const uint32_t dy = (pr >> 16) & 0x3ffu;
         uint8_t *orow = dst + (size_t)(pr & 0xffffu) * wf.dst_linesize;
         // (1) boxes one column wide, from registers: a lane has both of their columns, or takes
         // the left one from its neighbour (the first column of a strip never ends such a box:
         // its left column lies in the other strip)
-        if (any_unit) {
+        if (any_unit && !(a.ablate & 2048)) {
           if (dy == 1u) {  // the fovea: a reduced pixel IS a source pixel
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -416,7 +439,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
         }
         // (2) wider boxes and the columns of boxes that straddle two strips: D row through the
         // staging slice (its reads have returned)
-        if (needs_d) {
+        if (needs_d && !(a.ablate & 4096)) {
           lds_write_b128(mine + lane * 48, u32x4{acc[0] - snap[0], acc[1] - snap[1],
                                                   acc[2] - snap[2], acc[3] - snap[3]});
           lds_write_b128(mine + lane * 48 + 16, u32x4{acc[4] - snap[4], acc[5] - snap[5],
@@ -476,6 +499,9 @@ static size_t band_plan_lds_bytes(int height, int out_w, int out_h) {
   const int plan_stride = ((height + kRowUnroll - 1) / kRowUnroll) * kRowUnroll;
   return (size_t)plan_stride * 4 + (size_t)((out_w + 2) & ~1) * 2 + (size_t)((out_h + 2) & ~1) * 2;
 }
+static size_t band_plan_lds_bytes(int width, int height, int out_w, int out_h) {
+  return band_plan_lds_bytes(height, out_w, out_h) + (size_t)((width + kStripPx - 1) / kStripPx) * 1024;
+}
 bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int height,
                                           int linesize, int out_w, int out_h, int dst_linesize) {
   return ctx->opt_fuse_band != 0 && linesize / width == 4 && linesize % 16 == 0 &&
@@ -483,7 +509,7 @@ bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int he
          (size_t)width * height * 3 < ((size_t)1 << 31) && out_w < 65536 && out_h < 65536 &&
          (width + kStripPx - 1) / kStripPx <= kFixCols / 4 && dst_linesize % 4 == 0 &&
          dst_linesize >= 4 * out_w &&
-         band_plan_lds_bytes(height, out_w, out_h) <= 60 * 1024;  // the plan kernel's LDS
+         band_plan_lds_bytes(width, height, out_w, out_h) <= 62 * 1024;  // the plan kernel's LDS
 }
 
 // f360_satdec_encode_sample_frames on the three-kernel encoder: one plan launch and one fix-up
@@ -551,7 +577,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
     {
       f360::KernelSpan span(ctx, f360::kWalkFusePlan, prof, n);
       hipLaunchKernelGGL(band_fuse_plan_kernel, dim3(n), dim3(256),
-                         band_plan_lds_bytes(height, fuse.out_w, fuse.out_h), ctx->stream, wf,
+                         band_plan_lds_bytes(width, height, fuse.out_w, fuse.out_h), ctx->stream, wf,
                          width, height);
     }
     for (int k0 = 0; k0 < n; k0 += per_launch) {

@@ -19,10 +19,10 @@ from test_gpu_fuse import GAZES, _run
 pytestmark = pytest.mark.gpu
 
 
-def _ran_band_writer(ctx, call):
+def _ran_band_writer(ctx, call, calls=1):
     """Runs `call` as a sampled call and returns the kernels it launched."""
     ctx.profile_reset()
-    ctx.profile_arm(1)
+    ctx.profile_arm(calls)
     out = call()
     ctx.finish()
     return out, set(ctx.profile_read().keys())
@@ -104,7 +104,8 @@ def test_walker_one_pass_rare_branches(f360, gpu_ctx, oracle, force):
 def test_band_switch_off_is_the_two_calls(f360, gpu_ctx, oracle):
     gpu_ctx.set_option("fuse.band", 0)
     try:
-        bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(f360, gpu_ctx, oracle, 640, 320, GAZES[:3]))
+        bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(f360, gpu_ctx, oracle, 640, 320, GAZES[:3]),
+                                        calls=2)  # (the encode call and the sample call)
         assert bad == []
         assert "sat_write_fuse_kernel" not in kernels and "sample_rect_kernel" in kernels
     finally:
