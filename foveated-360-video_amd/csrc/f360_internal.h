@@ -203,6 +203,13 @@ struct f360_ctx {
   // target geometry; a debug word (rejected pixels of the last counted launch)
   int gn_gw = 0, gn_gh = 0, gn_cus = 0, gn_wg_per_cu = 0;
   f360::DevBuf gn_gtab, gn_counters;
+  // Side stream of batched calls that pipeline their frames (f360::side_stream): frame k + 1's
+  // reducer and carry pass run beside frame k's table writer.  Created on first use; forked
+  // from and joined back into `stream` with the two events inside the call, so from outside the
+  // call is still "enqueue on one in-order stream".
+  hipStream_t side = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  int opt_pipeline = 1;  // "sat.pipeline": batched calls on the three-kernel encoder use the side stream (0 = one stream)
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;
   std::vector<f360::ProfSpan> prof_pending;
@@ -217,17 +224,17 @@ namespace f360 {
 // current call is being sampled.
 class KernelSpan {
  public:
-  KernelSpan(f360_ctx *ctx, int kid, bool on, int frames = 1)
-      : ctx_(ctx), kid_(kid), on_(on), frames_(frames) {
+  KernelSpan(f360_ctx *ctx, int kid, bool on, int frames = 1, hipStream_t stream = nullptr)
+      : ctx_(ctx), kid_(kid), on_(on), frames_(frames), stream_(stream ? stream : ctx->stream) {
     if (!on_) return;
     a_ = take();
     b_ = take();
     if (!a_ || !b_) { on_ = false; return; }
-    (void)hipEventRecord(a_, ctx_->stream);
+    (void)hipEventRecord(a_, stream_);
   }
   ~KernelSpan() {
     if (!on_) return;
-    (void)hipEventRecord(b_, ctx_->stream);
+    (void)hipEventRecord(b_, stream_);
     ctx_->prof_pending.push_back(ProfSpan{kid_, a_, b_, frames_});
   }
  private:
@@ -245,8 +252,12 @@ class KernelSpan {
   int kid_;
   bool on_;
   int frames_;
+  hipStream_t stream_;
   hipEvent_t a_ = nullptr, b_ = nullptr;
 };
+// The context's side stream and its fork / join events, created on first use (null + error set
+// on failure).
+int side_stream(f360_ctx *ctx);
 // true when this call is sampled; consumes one armed call
 inline bool take_profile_slot(f360_ctx *ctx) {
   if (ctx->prof_armed <= 0) return false;
@@ -293,6 +304,8 @@ bool sat_encode_sample_applies(const f360_ctx *ctx, int count, int width, int he
 int sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats,
                            const uint8_t *const *srcs, const YuvPlanes *yuvs, int width,
                            int height, int linesize, const SatFuse &fuse, bool prof);
+// Makes the three-kernel encoder's scratch hold `frames` slices of this geometry (sat_three.hip).
+int sat_encode_reserve(f360_ctx *ctx, int width, int height, int frames);
 // The same for calls the read-once encoder does not take (1 .. 22 8K frames): the three-kernel
 // encoder with its table writer in one-pass form (sat_band_fuse.hip); RGB0 frames.
 bool sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int height, int linesize,

@@ -36,6 +36,14 @@ void DevBuf::release() {
 
 using f360::set_error;
 
+int f360::side_stream(f360_ctx *ctx) {
+  if (ctx->side) return F360_OK;
+  F360_HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  F360_HIP_TRY(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+  F360_HIP_TRY(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+  return F360_OK;
+}
+
 extern "C" {
 
 int f360_version(void) { return F360_VERSION_MAJOR * 100 + F360_VERSION_MINOR; }
@@ -123,6 +131,12 @@ int f360_ctx_destroy(f360_ctx *ctx) {
     (void)hipEventDestroy(s.b);
   }
   for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
+  if (ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipStreamDestroy(ctx->side);
+  }
+  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+  if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return F360_OK;
@@ -277,6 +291,7 @@ static const OptionSlot kOptions[] = {
     {"fov.piggyback", &f360_ctx::opt_fov_piggyback},
     {"fuse.walk", &f360_ctx::opt_fuse_walk},
     {"fuse.band", &f360_ctx::opt_fuse_band},
+    {"sat.pipeline", &f360_ctx::opt_pipeline},
     {"debug.fuse_force", &f360_ctx::opt_fuse_force},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},

@@ -35,6 +35,33 @@ using namespace f360::sat;
 
 namespace {
 
+#ifndef F360_BAND_PX_BITS
+#define F360_BAND_PX_BITS " nt"  // cache bits of the reduced-pixel stores (A/B builds)
+#endif
+__device__ __forceinline__ void band_store_rgb(uint8_t *row, uint32_t off, uint32_t rg, uint32_t b,
+                                               bool whole = false) {
+  if (whole) {  // (timing experiment, debug.ablate 16384: ONE four-byte store, clobbers byte 3)
+    asm volatile("global_store_dword %0, %1, %2" F360_BAND_PX_BITS ::"v"(off), "v"(rg | (b << 16)), "s"(row) : "memory");
+    return;
+  }
+  asm volatile("global_store_short %0, %1, %3" F360_BAND_PX_BITS "\n\t"
+               "global_store_byte %0, %2, %3 offset:2" F360_BAND_PX_BITS ::"v"(off),
+               "v"(rg), "v"(b), "s"(row)
+               : "memory");
+}
+// a source pixel as it is: R, G from the low half, B from byte 2
+__device__ __forceinline__ void band_store_px(uint8_t *row, uint32_t off, uint32_t px,
+                                              bool whole = false) {
+  if (whole) {
+    asm volatile("global_store_dword %0, %1, %2" F360_BAND_PX_BITS ::"v"(off), "v"(px), "s"(row) : "memory");
+    return;
+  }
+  asm volatile("global_store_short %0, %1, %2" F360_BAND_PX_BITS "\n\t"
+               "global_store_byte_d16_hi %0, %1, %2 offset:2" F360_BAND_PX_BITS ::"v"(off),
+               "v"(px), "s"(row)
+               : "memory");
+}
+
 // ---- the plan of a frame: row marks, straddling pixels, per-strip pixel maps -----------------
 // One workgroup per frame; the decoder's two grid axes are staged in LDS first (every box rule
 // below is a chain of grid look-ups, and from global memory each link is a round trip), the
@@ -150,8 +177,12 @@ __global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, 
         }
       }
     }
-    __syncthreads();
+    // (a bare barrier: what must be ordered between chunks are the LDS atomics, whose results
+    // the threads have waited for; __syncthreads() would also wait for the list stores above to
+    // be acknowledged -- 17 memory round trips in a row, 20 of this kernel's 24 us)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  __syncthreads();
   uint32_t *plan = wf.rowplan + (size_t)f * wf.plan_stride;
   for (int y = t; y < wf.plan_stride; y += 256) plan[y] = lplan[y];
   for (int k = t; k < nstrips * 256; k += 256)
@@ -175,7 +206,7 @@ __global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, 
 // flight between two of them, so the compiler may move or copy their results as it likes.
 __device__ __forceinline__ void band_emit_wide(uint32_t pr, uint8_t *orow, uint32_t dlds,
                                                uint32_t elds, int lane, int n_ent, u32x2 e0,
-                                               uint32_t max_dxw) {
+                                               uint32_t max_dxw, bool no_px) {
   const uint32_t dy = (pr >> 16) & 0x3ffu;
   const bool quick = dy * max_dxw <= 2048u;  // the float quotient is exact (tests/test_fuse_div.py)
   const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
@@ -215,10 +246,10 @@ __device__ __forceinline__ void band_emit_wide(uint32_t pr, uint8_t *orow, uint3
       const uint32_t qx = (uint32_t)__builtin_fmaf((float)n.x, inv, 0x1p-12f);
       const uint32_t qy = (uint32_t)__builtin_fmaf((float)n.y, inv, 0x1p-12f);
       const uint32_t qz = (uint32_t)__builtin_fmaf((float)n.z, inv, 0x1p-12f);
-      if (valid) fuse_store_rgb(orow, estore, qx | (qy << 8), qz);
+      if (valid && !no_px) band_store_rgb(orow, estore, qx | (qy << 8), qz);
     } else {
       const uint3 q = fuse_div3(n, dxw * dy);
-      if (valid) fuse_store_rgb(orow, estore, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
+      if (valid && !no_px) band_store_rgb(orow, estore, (q.x & 0xffu) | ((q.y & 0xffu) << 8), q.z);
     }
   }
 }
@@ -230,9 +261,10 @@ template <int SRC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
     const EncodeArgs a, const EncodeBatch eb, const WalkFuse wf, int frame0) {
   static_assert(SRC == kSrcRgb0, "the band writer's one pass takes RGB0 frames");
-  // per wave: 3 KiB store staging / D row, then the strip's list of wide boxes past the first
-  // round (8 bytes each; 6 KiB, hardly ever used)
-  constexpr int kWaveDwords = 3 * kStripPx + 2 * kFuseEntries;
+  // per wave: 3 KiB store staging / D row, 1 KiB to turn a row of reduced pixels around (below),
+  // then the strip's list of wide boxes past the first round (8 bytes each; 6 KiB, hardly ever
+  // used)
+  constexpr int kWaveDwords = 4 * kStripPx + 2 * kFuseEntries;
   __shared__ __attribute__((aligned(16))) uint32_t stage[kWavesPerBlock * kWaveDwords];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -245,7 +277,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
   const int sb = band / a.sb_bands;
   const int f = frame0 + (a.nbatch != 0 ? (int)blockIdx.y : 0);
   const uint32_t mine = (uint32_t)reinterpret_cast<uintptr_t>(stage) + wave * kWaveDwords * 4;
-  const uint32_t elds = mine + 3 * kStripPx * 4;
+  const uint32_t tlds = mine + 3 * kStripPx * 4;
+  const uint32_t elds = tlds + kStripPx * 4;
 
   const int y_end = min((band + 1) * a.band_rows, a.height);
   const uint32_t *rc = a.rowcarry + fr.ws + (size_t)strip * a.height * 3;
@@ -268,13 +301,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
   const uint32_t *ent = wf.ent + ((size_t)f * a.nstrips + strip) * kBandEntStride;
   const int n_ent = (int)ent[0];
   const uint32_t max_dxw = ent[1];
-  // this lane's four columns: where the one-column box that ends there goes (byte offset in the
-  // reduced row), ~0 if none
+  // Where the one-column box that ends at a column goes (byte offset in the reduced row, ~0 if
+  // none).  A lane COMPUTES the pixels of its own four columns (4 * lane + k) but STORES those of
+  // columns lane + 64 k: turned around through LDS, a store instruction writes 64 neighbouring
+  // pixels (two lines) instead of every fourth pixel of 256 (all eight lines of the row segment,
+  // each of which four instructions then fill piecemeal) -- the table rows' re-staging over again.
   uint32_t ux[4];
-  {
-    const uint4 u = *reinterpret_cast<const uint4 *>(ent + kBandEntUnit + lane * 4);
-    ux[0] = u.x, ux[1] = u.y, ux[2] = u.z, ux[3] = u.w;
-  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ux[k] = ent[kBandEntUnit + lane + 64 * k];
   const bool any_unit = __any((ux[0] & ux[1] & ux[2] & ux[3]) != kNoPixel);
   u32x2 e0;
   {
@@ -313,6 +347,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
   }
   const bool exports = __any(xslot[0] >= 0) || __any(xslot[1] >= 0) || __any(xslot[2] >= 0);
   const bool needs_d = n_ent > 0 || exports;  // (else the D row never goes through LDS)
+  const bool no_px = a.ablate & 8192;         // (timing experiment: everything but the pixel stores)
   uint8_t *dst = wf.dst[f];
   uint32_t *side = wf.side + (size_t)f * wf.side_stride;
 
@@ -397,7 +432,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
       }
       const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane((int)carry, 32 + r);  // plan[y + r]
       // (debug.ablate, timing experiments: 1024 no emit at all, 2048 no one-column boxes,
-      // 4096 no wide boxes / side rows)
+      // 4096 no wide boxes / side rows, 8192 no pixel stores)
       if ((pr & kFuseEmit) && !(a.ablate & 1024)) {
         const uint32_t dy = (pr >> 16) & 0x3ffu;
         uint8_t *orow = dst + (size_t)(pr & 0xffffu) * wf.dst_linesize;
@@ -405,24 +440,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
         // the left one from its neighbour (the first column of a strip never ends such a box:
         // its left column lies in the other strip)
         if (any_unit && !(a.ablate & 2048)) {
+          uint32_t mypx[4];  // columns 4 * lane + k, packed R | G << 8 | B << 16
           if (dy == 1u) {  // the fovea: a reduced pixel IS a source pixel
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (ux[k] != kNoPixel)
-                asm volatile(
-                    "global_store_short %0, %1, %2 nt\n\t"
-                    "global_store_byte_d16_hi %0, %1, %2 offset:2 nt" ::"v"(ux[k]),
-                    "v"(px[k]), "s"(orow)
-                    : "memory");
+            for (int k = 0; k < 4; ++k) mypx[k] = px[k];
           } else {
             // D = row - snapshot; box = D[x] - D[x - 1]; dy <= band height: the float quotient
             // is exact (tests/test_fuse_div.py)
             const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
             uint32_t left[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch)  // D of the lane to the left's fourth column
+            for (int ch = 0; ch < 3; ++ch) {  // D of the lane to the left's fourth column
               left[ch] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(acc[9 + ch] - snap[9 + ch]),
                                                                0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+              // (kept a plain v_mov_dpp: hipcc 7.2 folds the move into the subtraction below as
+              // v_subrev_u32_dpp, and that form returned wrong differences on gfx950 -- found by
+              // the parity tests, like the byte-packing instruction check_isa.py bans)
+              asm volatile("" : "+v"(left[ch]));
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               uint32_t q[3];
@@ -433,9 +468,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
                 left[ch] = d;
                 q[ch] = (uint32_t)__builtin_fmaf((float)n, inv_dy, 0x1p-12f);
               }
-              if (ux[k] != kNoPixel) fuse_store_rgb(orow, ux[k], q[0] | (q[1] << 8), q[2]);
+              mypx[k] = q[0] | (q[1] << 8) | (q[2] << 16);
             }
           }
+          // turn the row segment around: in as column 4 * lane + k, out as column lane + 64 k
+          u32x2 t01, t23;
+          asm volatile(
+              "ds_write_b128 %2, %3\n\t"
+              "ds_read2st64_b32 %0, %4 offset1:1\n\t"
+              "ds_read2st64_b32 %1, %4 offset0:2 offset1:3\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(t01), "=&v"(t23)
+              : "v"(tlds + lane * 16), "v"(u32x4{mypx[0], mypx[1], mypx[2], mypx[3]}),
+                "v"(tlds + lane * 4)
+              : "memory");
+          const uint32_t out[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (ux[k] != kNoPixel && !no_px) band_store_px(orow, ux[k], out[k], a.ablate & 16384);
         }
         // (2) wider boxes and the columns of boxes that straddle two strips: D row through the
         // staging slice (its reads have returned)
@@ -446,7 +496,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
                                                        acc[6] - snap[6], acc[7] - snap[7]});
           lds_write_b128(mine + lane * 48 + 32, u32x4{acc[8] - snap[8], acc[9] - snap[9],
                                                        acc[10] - snap[10], acc[11] - snap[11]});
-          if (n_ent > 0) band_emit_wide(pr, orow, mine, elds, lane, n_ent, e0, max_dxw);
+          if (n_ent > 0) band_emit_wide(pr, orow, mine, elds, lane, n_ent, e0, max_dxw, no_px);
           if (exports) {
             u32x2 x01[3];
             uint32_t x2[3];
@@ -490,7 +540,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
 void f360::sat::launch_write_fuse(f360_ctx *ctx, const EncodeArgs &a, const EncodeBatch &eb,
                                   dim3 grid, const f360::SatBandFuse &bf) {
   hipLaunchKernelGGL((sat_write_fuse_kernel<kSrcRgb0>), grid, dim3(64 * kWavesPerBlock), 0,
-                     ctx->stream, a, eb, bf.wf, bf.frame0);
+                     bf.stream ? bf.stream : ctx->stream, a, eb, bf.wf, bf.frame0);
 }
 
 // Whether f360_satdec_encode_sample_frames can take the band writer's one pass for this call
@@ -580,17 +630,45 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
                          band_plan_lds_bytes(width, height, fuse.out_w, fuse.out_h), ctx->stream, wf,
                          width, height);
     }
-    for (int k0 = 0; k0 < n; k0 += per_launch) {
+    // Launch groups alternate between the context's stream and its side stream ("sat.pipeline"),
+    // each with its own slice of the encoder's scratch: a group is a chain reducer -> carry pass
+    // -> writer, and beside one group's writer (write-bound) the other's reducer (read-bound,
+    // a third of a frame's time) and carry pass (latency-bound) run for free -- the frames of a
+    // call are independent.  Forked after the plan kernel, joined before the fix-up: from
+    // outside the call is still work enqueued on one in-order stream (and capturable as such).
+    const int ngroups = (n + per_launch - 1) / per_launch;
+    const bool pipelined = ctx->opt_pipeline != 0 && ngroups >= 2;
+    if (pipelined) {
+      st = f360::side_stream(ctx);
+      if (st != F360_OK) return st;
+      // (both slices exist before anything is forked: growing the scratch synchronises)
+      st = f360::sat_encode_reserve(ctx, width, height, 2 * std::min(per_launch, n));
+      if (st != F360_OK) return st;
+      F360_HIP_TRY(hipEventRecord(ctx->side_fork, ctx->stream));
+      F360_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
+    }
+    bf.slots = pipelined ? 2 : 1;
+    bf.slot_frames = std::min(per_launch, n);
+    for (int k0 = 0, g = 0; k0 < n; k0 += per_launch, ++g) {
       const int m = std::min(n - k0, per_launch);
       bf.frame0 = k0;
+      bf.slot = pipelined ? g & 1 : 0;
+      bf.stream = pipelined && (g & 1) ? ctx->side : nullptr;
+      // (every group as large as the first: the slices are carved for that size)
       st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr, nullptr,
                                  m, sats + c0 + k0, srcs + c0 + k0, prof ? 1 : 0, nullptr, &bf);
-      if (st != F360_OK) return st;
+      if (st != F360_OK) break;
       if (ctx->enc.band_rows != band_rows) {  // (cannot happen: same geometry, same options)
         f360::set_error("f360_satdec_encode_sample_frames: the encoder plan changed under the call");
-        return F360_ERR_INVALID_ARG;
+        st = F360_ERR_INVALID_ARG;
+        break;
       }
     }
+    if (pipelined) {  // (joined whatever happened above: nothing may be left running on the side)
+      F360_HIP_TRY(hipEventRecord(ctx->side_join, ctx->side));
+      F360_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    }
+    if (st != F360_OK) return st;
     {
       f360::KernelSpan span(ctx, f360::kWalkFuseFix, prof, n);
       hipLaunchKernelGGL(walk_fuse_fix_kernel<0>,

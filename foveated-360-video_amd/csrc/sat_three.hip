@@ -574,6 +574,10 @@ extern "C" int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height) {
 
 namespace f360 {
 
+int sat_encode_reserve(f360_ctx *ctx, int width, int height, int frames) {
+  return ensure_plan(ctx, width, height, false, frames);
+}
+
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
                     int count, uint32_t *const *sats, const uint8_t *const *srcs, int profile,
@@ -622,9 +626,16 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   }
   F360_REQUIRE((size_t)width * height * 3 < ((size_t)1 << 31),
                "f360_sat_encode: frame too large for 32-bit element indices");
-  int st = ensure_plan(ctx, width, height, yuv != nullptr, count > 0 ? count : 1);
+  const int slots = band_fuse ? band_fuse->slots : 1, slot = band_fuse ? band_fuse->slot : 0;
+  hipStream_t stream = band_fuse && band_fuse->stream ? band_fuse->stream : ctx->stream;
+  const int slot_frames = band_fuse && band_fuse->slot_frames > 0 ? band_fuse->slot_frames
+                                                                  : (count > 0 ? count : 1);
+  int st = ensure_plan(ctx, width, height, yuv != nullptr, slot_frames * slots);
   if (st != F360_OK) return st;
   const f360::SatEncodePlan &p = ctx->enc;
+  // (a pipelined call's launch groups alternate between slices of the scratch: group g + 1's
+  // reducer writes while group g's table writer still reads)
+  const size_t ws_off = (size_t)slot * slot_frames * p.ws_stride;
 
   EncodeArgs a;
   a.sat = sat_dev;
@@ -639,13 +650,13 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   a.nbands = p.nbands;
   a.nsb = p.nsb;
   a.wp3 = p.wp3;
-  a.lp = p.lp;
-  a.sbtotal = p.sbtotal;
-  a.sbprefix = p.sbprefix;
-  a.rowsum = p.rowsum;
-  a.rowcarry = p.rowcarry;
-  a.tiletotal = p.tiletotal;
-  a.tprefix = p.tprefix;
+  a.lp = p.lp + ws_off;
+  a.sbtotal = p.sbtotal + ws_off;
+  a.sbprefix = p.sbprefix + ws_off;
+  a.rowsum = p.rowsum + ws_off;
+  a.rowcarry = p.rowcarry + ws_off;
+  a.tiletotal = p.tiletotal + ws_off;
+  a.tprefix = p.tprefix + ws_off;
   a.ablate = ctx->opt_ablate;
   a.xmap = emit ? emit->xmap : nullptr;
   a.ymap = emit ? emit->ymap : nullptr;
@@ -684,18 +695,18 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   const int blocks1 = reduce_blocks + (a.has_maps ? 2 : 0);
 
   {
-    f360::KernelSpan span(ctx, f360::kSatReduce, prof, (int)frames);
+    f360::KernelSpan span(ctx, f360::kSatReduce, prof, (int)frames, stream);
     if (yuv_src == kSrcYuvSwsX86)
       hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsX86>, dim3(blocks1, frames), block, 0,
-                         ctx->stream, a, eb);
+                         stream, a, eb);
     else if (yuv_src == kSrcYuvSwsC)
       hipLaunchKernelGGL(sat_reduce_kernel<kSrcYuvSwsC>, dim3(blocks1, frames), block, 0,
-                         ctx->stream, a, eb);
+                         stream, a, eb);
     else if (vec)
-      hipLaunchKernelGGL(sat_reduce_kernel<kSrcRgb0>, dim3(blocks1, frames), block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL(sat_reduce_kernel<kSrcRgb0>, dim3(blocks1, frames), block, 0, stream, a, eb);
     else
       hipLaunchKernelGGL(sat_reduce_kernel<kSrcBytes>, dim3(blocks1, frames), block, 0,
-                         ctx->stream, a, eb);
+                         stream, a, eb);
   }
 
   if (ctx->opt_ablate & 8) return F360_OK;  // timing experiments: reducer only
@@ -703,41 +714,41 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
     const int parts = K > 128 ? 1 : (K + 31) / 32, cols = 256 / (parts < 1 ? 1 : parts);
     return ScanSeg{in, out, n, K, (n + cols - 1) / cols};
   };
-  ScanSeg sa = seg(p.sbtotal, p.sbprefix, p.wp3, p.nsb);
-  ScanSeg sb = seg(p.rowsum, p.rowcarry, height * 3, p.nstrips);
-  ScanSeg sc = seg(p.tiletotal, p.tprefix, p.nbands * 3, p.nstrips);
+  ScanSeg sa = seg(a.sbtotal, a.sbprefix, p.wp3, p.nsb);
+  ScanSeg sb = seg(a.rowsum, a.rowcarry, height * 3, p.nstrips);
+  ScanSeg sc = seg(a.tiletotal, a.tprefix, p.nbands * 3, p.nstrips);
   {
-    f360::KernelSpan span(ctx, f360::kSatCarry, prof, (int)frames);
+    f360::KernelSpan span(ctx, f360::kSatCarry, prof, (int)frames, stream);
     hipLaunchKernelGGL(sat_carry_kernel,
                        dim3(sa.nblocks + sb.nblocks + sc.nblocks, frames), dim3(256), 0,
-                       ctx->stream, sa, sb, sc, p.ws_stride);
+                       stream, sa, sb, sc, p.ws_stride);
   }
   if (band_fuse) {  // the writer also emits the reduced pixels of its tile (sat_band_fuse.hip)
     F360_REQUIRE(vec && !emit && count > 0, "sat_encode_impl: the one-pass writer takes batches of aligned RGB0 frames");
-    f360::KernelSpan span(ctx, f360::kSatWriteFuse, prof, (int)frames);
+    f360::KernelSpan span(ctx, f360::kSatWriteFuse, prof, (int)frames, stream);
     launch_write_fuse(ctx, a, eb,
                       dim3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock, frames),
                       *band_fuse);
   } else {
-    f360::KernelSpan span(ctx, f360::kSatWrite, prof, (int)frames);
+    f360::KernelSpan span(ctx, f360::kSatWrite, prof, (int)frames, stream);
     const dim3 grid3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock, frames);
     if (yuv_src == kSrcYuvSwsX86 && emit)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsX86, 2>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsX86, 2>), grid3, block, 0, stream, a, eb);
     else if (yuv_src == kSrcYuvSwsX86)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsX86, 1>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsX86, 1>), grid3, block, 0, stream, a, eb);
     else if (yuv_src == kSrcYuvSwsC && emit)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsC, 2>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsC, 2>), grid3, block, 0, stream, a, eb);
     else if (yuv_src == kSrcYuvSwsC)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsC, 1>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcYuvSwsC, 1>), grid3, block, 0, stream, a, eb);
     else if (emit && vec)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 2>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 2>), grid3, block, 0, stream, a, eb);
     else if (emit)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 2>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 2>), grid3, block, 0, stream, a, eb);
     else if (!vec)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 0>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcBytes, 0>), grid3, block, 0, stream, a, eb);
     else  // (direct 48-byte-stride stores for RGB0 frames, "sat.store" = 0, were an A/B switch
           // until round 4: 136 against 88 us at 8K)
-      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 1>), grid3, block, 0, ctx->stream, a, eb);
+      hipLaunchKernelGGL((sat_write_kernel<kSrcRgb0, 1>), grid3, block, 0, stream, a, eb);
   }
   F360_HIP_TRY(hipGetLastError());
   return F360_OK;

@@ -6,8 +6,8 @@ tag=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${tag}_band_ablate.txt
 : > $O
-for ab in 0 1024 2048 4096 6144; do
-  for fpc in 1 8; do
+for ab in ${ABLATES:-0 1024 2048 4096 6144 8192}; do
+  for fpc in ${FPCS:-1 8}; do
     echo "== debug.ablate=$ab frames-per-call $fpc" >> $O
     python $R/bench.py --steps 6 --warmup 1 --batch 16 --frames-per-call $fpc --one-pass on \
         --no-cpu-baseline --no-variants --no-verify --opt debug.ablate=$ab 2>/dev/null |

@@ -143,6 +143,12 @@ def main():
                                     f"({len(min(cand, key=len))} instructions)")
                     if not any(re.match(r"s_waitcnt vmcnt\([1-9]", t) for t in texts):
                         perf.append(f"{name}: no counted vmcnt wait left")
+                    # hipcc 7.2 folds the wave-shift move of the one-column boxes into the
+                    # subtraction that follows (v_subrev_u32_dpp ... wave_shr:1); that form gave
+                    # wrong differences on gfx950 (parity tests, round 5); the kernel pins the move
+                    if any(re.match(r"v_(sub|subrev|add)\w*_dpp .*wave_sh", t) for t in texts):
+                        errors.append(f"{name}: arithmetic folded into a wave-shift DPP "
+                                      f"(known-bad on gfx950; keep the v_mov_b32_dpp)")
                 if re.search(r"sat_reduce_kernelILi[123]EE", name):
                     seen.add("reducer")
                     # the steady-state loop: a batch of >= 8 row loads, waits that count the
