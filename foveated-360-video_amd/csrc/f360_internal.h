@@ -255,9 +255,6 @@ class KernelSpan {
   hipStream_t stream_;
   hipEvent_t a_ = nullptr, b_ = nullptr;
 };
-// The context's side stream and its fork / join events, created on first use (null + error set
-// on failure).
-int side_stream(f360_ctx *ctx);
 // true when this call is sampled; consumes one armed call
 inline bool take_profile_slot(f360_ctx *ctx) {
   if (ctx->prof_armed <= 0) return false;
@@ -275,7 +272,18 @@ struct SatEmit {
   int corner_stride;
   const FovMaps *maps;  // non-null: the reducer's launch also computes the lattice maps
 };
+// The context's side stream and its fork / join events, created on first use (null + error set
+// on failure).
+int side_stream(f360_ctx *ctx);
+// Makes the three-kernel encoder's scratch hold `frames` slices of this geometry (sat_three.hip).
+int sat_encode_reserve(f360_ctx *ctx, int width, int height, int frames, bool planar = false);
 struct SatBandFuse;  // sat_fuse_dev.h: the table writer also emits the reduced pixels of its tile
+// Where one launch group of a pipelined batched call goes: the stream (null: the context's) and
+// which of the `slots` slices of the encoder's scratch, each `slot_frames` frames large, it uses.
+struct SatLaunch {
+  hipStream_t stream = nullptr;
+  int slot = 0, slots = 1, slot_frames = 0;  // (slot_frames 0: the launch's own frame count)
+};
 // `yuv` non-null: the pixels come from three planes (src_dev / linesize unused)
 // `count` > 0: a batch of frames of one geometry (tables sats[k] of sources srcs[k]; sat_dev /
 // src_dev unused, no emit; `yuvs` non-null: frame k's planes, all with yuvs[0]'s linesizes).  `profile`: -1 = take a profile slot if one is armed,
@@ -284,7 +292,44 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
                     int count = 0, uint32_t *const *sats = nullptr,
                     const uint8_t *const *srcs = nullptr, int profile = -1,
-                    const YuvPlanes *yuvs = nullptr, const SatBandFuse *band_fuse = nullptr);
+                    const YuvPlanes *yuvs = nullptr, const SatBandFuse *band_fuse = nullptr,
+                    const SatLaunch *where = nullptr);
+// The launch groups of a batched call on the three-kernel encoder, `ngroups` of at most
+// `group_frames` frames: group g is a chain reducer -> carry pass -> table writer, the frames of
+// a call are independent, and beside one group's writer (write-bound) the next group's reducer
+// (read-bound, a third of a frame's time) and carry pass (latency-bound) run almost for free.
+// So the groups alternate between the context's stream and its side stream ("sat.pipeline"),
+// each with its own slice of the encoder's scratch; forked here, joined before returning: from
+// outside the call is still work enqueued on one in-order stream (and capturable as such).
+// `launch(g, where)` enqueues group g.
+template <class Launch>
+int sat_pipelined_groups(f360_ctx *ctx, int width, int height, bool planar, int ngroups,
+                         int group_frames, Launch &&launch) {
+  const bool pipelined = ctx->opt_pipeline != 0 && ngroups >= 2;
+  int st = F360_OK;
+  if (pipelined) {
+    st = side_stream(ctx);
+    if (st != F360_OK) return st;
+    // (both slices exist before anything is forked: growing the scratch synchronises)
+    st = sat_encode_reserve(ctx, width, height, 2 * group_frames, planar);
+    if (st != F360_OK) return st;
+    F360_HIP_TRY(hipEventRecord(ctx->side_fork, ctx->stream));
+    F360_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
+  }
+  SatLaunch where;
+  where.slots = pipelined ? 2 : 1;
+  where.slot_frames = group_frames;
+  for (int g = 0; g < ngroups && st == F360_OK; ++g) {
+    where.slot = pipelined ? g & 1 : 0;
+    where.stream = pipelined && (g & 1) ? ctx->side : nullptr;
+    st = launch(g, where);
+  }
+  if (pipelined) {  // (joined whatever happened above: nothing may be left running on the side)
+    F360_HIP_TRY(hipEventRecord(ctx->side_join, ctx->side));
+    F360_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+  }
+  return st;
+}
 }  // namespace f360
 
 namespace f360 {
@@ -304,8 +349,11 @@ bool sat_encode_sample_applies(const f360_ctx *ctx, int count, int width, int he
 int sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats,
                            const uint8_t *const *srcs, const YuvPlanes *yuvs, int width,
                            int height, int linesize, const SatFuse &fuse, bool prof);
+// The context's side stream and its fork / join events, created on first use (null + error set
+// on failure).
+int side_stream(f360_ctx *ctx);
 // Makes the three-kernel encoder's scratch hold `frames` slices of this geometry (sat_three.hip).
-int sat_encode_reserve(f360_ctx *ctx, int width, int height, int frames);
+
 // The same for calls the read-once encoder does not take (1 .. 22 8K frames): the three-kernel
 // encoder with its table writer in one-pass form (sat_band_fuse.hip); RGB0 frames.
 bool sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int height, int linesize,

@@ -537,10 +537,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
 
 // The table writer's launch of a three-kernel encode (sat_three.hip: sat_encode_impl), one-pass
 // form.  `grid` / frames as for sat_write_kernel.
-void f360::sat::launch_write_fuse(f360_ctx *ctx, const EncodeArgs &a, const EncodeBatch &eb,
-                                  dim3 grid, const f360::SatBandFuse &bf) {
-  hipLaunchKernelGGL((sat_write_fuse_kernel<kSrcRgb0>), grid, dim3(64 * kWavesPerBlock), 0,
-                     bf.stream ? bf.stream : ctx->stream, a, eb, bf.wf, bf.frame0);
+void f360::sat::launch_write_fuse(f360_ctx *ctx, hipStream_t stream, const EncodeArgs &a,
+                                  const EncodeBatch &eb, dim3 grid, const f360::SatBandFuse &bf) {
+  (void)ctx;
+  hipLaunchKernelGGL((sat_write_fuse_kernel<kSrcRgb0>), grid, dim3(64 * kWavesPerBlock), 0, stream,
+                     a, eb, bf.wf, bf.frame0);
 }
 
 // Whether f360_satdec_encode_sample_frames can take the band writer's one pass for this call
@@ -630,44 +631,22 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
                          band_plan_lds_bytes(width, height, fuse.out_w, fuse.out_h), ctx->stream, wf,
                          width, height);
     }
-    // Launch groups alternate between the context's stream and its side stream ("sat.pipeline"),
-    // each with its own slice of the encoder's scratch: a group is a chain reducer -> carry pass
-    // -> writer, and beside one group's writer (write-bound) the other's reducer (read-bound,
-    // a third of a frame's time) and carry pass (latency-bound) run for free -- the frames of a
-    // call are independent.  Forked after the plan kernel, joined before the fix-up: from
-    // outside the call is still work enqueued on one in-order stream (and capturable as such).
-    const int ngroups = (n + per_launch - 1) / per_launch;
-    const bool pipelined = ctx->opt_pipeline != 0 && ngroups >= 2;
-    if (pipelined) {
-      st = f360::side_stream(ctx);
-      if (st != F360_OK) return st;
-      // (both slices exist before anything is forked: growing the scratch synchronises)
-      st = f360::sat_encode_reserve(ctx, width, height, 2 * std::min(per_launch, n));
-      if (st != F360_OK) return st;
-      F360_HIP_TRY(hipEventRecord(ctx->side_fork, ctx->stream));
-      F360_HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
-    }
-    bf.slots = pipelined ? 2 : 1;
-    bf.slot_frames = std::min(per_launch, n);
-    for (int k0 = 0, g = 0; k0 < n; k0 += per_launch, ++g) {
-      const int m = std::min(n - k0, per_launch);
-      bf.frame0 = k0;
-      bf.slot = pipelined ? g & 1 : 0;
-      bf.stream = pipelined && (g & 1) ? ctx->side : nullptr;
-      // (every group as large as the first: the slices are carved for that size)
-      st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr, nullptr,
-                                 m, sats + c0 + k0, srcs + c0 + k0, prof ? 1 : 0, nullptr, &bf);
-      if (st != F360_OK) break;
-      if (ctx->enc.band_rows != band_rows) {  // (cannot happen: same geometry, same options)
-        f360::set_error("f360_satdec_encode_sample_frames: the encoder plan changed under the call");
-        st = F360_ERR_INVALID_ARG;
-        break;
-      }
-    }
-    if (pipelined) {  // (joined whatever happened above: nothing may be left running on the side)
-      F360_HIP_TRY(hipEventRecord(ctx->side_join, ctx->side));
-      F360_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
-    }
+    // (launch groups alternate between the context's stream and its side stream, see
+    // sat_pipelined_groups: forked after the plan kernel, joined before the fix-up)
+    st = f360::sat_pipelined_groups(
+        ctx, width, height, false, (n + per_launch - 1) / per_launch, std::min(per_launch, n),
+        [&](int g, const f360::SatLaunch &where) {
+          const int k0 = g * per_launch, m = std::min(n - k0, per_launch);
+          bf.frame0 = k0;
+          const int e = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr,
+                                              nullptr, m, sats + c0 + k0, srcs + c0 + k0,
+                                              prof ? 1 : 0, nullptr, &bf, &where);
+          if (e == F360_OK && ctx->enc.band_rows != band_rows) {  // (cannot happen: same geometry)
+            f360::set_error("f360_satdec_encode_sample_frames: the encoder plan changed under the call");
+            return (int)F360_ERR_INVALID_ARG;
+          }
+          return e;
+        });
     if (st != F360_OK) return st;
     {
       f360::KernelSpan span(ctx, f360::kWalkFuseFix, prof, n);

@@ -72,15 +72,10 @@ struct WalkNoFuse {};
 struct SatBandFuse {
   sat::WalkFuse wf;
   int frame0;  // index of the launch's first frame in wf's per-frame arrays
-  // pipelined calls: the stream this launch group goes to (null: the context's), which of the
-  // `slots` slices of the encoder's scratch it uses, and whether the writer waits for nothing
-  // but its own stream (the reducer and carry pass of the NEXT group run beside it)
-  hipStream_t stream = nullptr;
-  int slot = 0, slots = 1, slot_frames = 0;  // (slot_frames: frames a slice holds; 0 = the launch's)
 };
 namespace sat {
-void launch_write_fuse(f360_ctx *ctx, const EncodeArgs &a, const EncodeBatch &eb, dim3 grid,
-                       const f360::SatBandFuse &bf);
+void launch_write_fuse(f360_ctx *ctx, hipStream_t stream, const EncodeArgs &a,
+                       const EncodeBatch &eb, dim3 grid, const f360::SatBandFuse &bf);
 template <bool FUSE> struct WalkFuseArg { typedef WalkNoFuse type; };
 template <> struct WalkFuseArg<true> { typedef WalkFuse type; };
 

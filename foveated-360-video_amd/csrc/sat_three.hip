@@ -574,14 +574,14 @@ extern "C" int f360_sat_encode_prepare(f360_ctx *ctx, int width, int height) {
 
 namespace f360 {
 
-int sat_encode_reserve(f360_ctx *ctx, int width, int height, int frames) {
-  return ensure_plan(ctx, width, height, false, frames);
+int sat_encode_reserve(f360_ctx *ctx, int width, int height, int frames, bool planar) {
+  return ensure_plan(ctx, width, height, planar, frames);
 }
 
 int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, int width,
                     int height, int linesize, const SatEmit *emit, const YuvPlanes *yuv,
                     int count, uint32_t *const *sats, const uint8_t *const *srcs, int profile,
-                    const YuvPlanes *yuvs, const SatBandFuse *band_fuse) {
+                    const YuvPlanes *yuvs, const SatBandFuse *band_fuse, const SatLaunch *where) {
   F360_REQUIRE(ctx, "f360_sat_encode: null context");
   F360_BIND_DEVICE(ctx);
   if (count > 0) {
@@ -626,10 +626,9 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   }
   F360_REQUIRE((size_t)width * height * 3 < ((size_t)1 << 31),
                "f360_sat_encode: frame too large for 32-bit element indices");
-  const int slots = band_fuse ? band_fuse->slots : 1, slot = band_fuse ? band_fuse->slot : 0;
-  hipStream_t stream = band_fuse && band_fuse->stream ? band_fuse->stream : ctx->stream;
-  const int slot_frames = band_fuse && band_fuse->slot_frames > 0 ? band_fuse->slot_frames
-                                                                  : (count > 0 ? count : 1);
+  const int slots = where ? where->slots : 1, slot = where ? where->slot : 0;
+  hipStream_t stream = where && where->stream ? where->stream : ctx->stream;
+  const int slot_frames = where && where->slot_frames > 0 ? where->slot_frames : (count > 0 ? count : 1);
   int st = ensure_plan(ctx, width, height, yuv != nullptr, slot_frames * slots);
   if (st != F360_OK) return st;
   const f360::SatEncodePlan &p = ctx->enc;
@@ -726,7 +725,7 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
   if (band_fuse) {  // the writer also emits the reduced pixels of its tile (sat_band_fuse.hip)
     F360_REQUIRE(vec && !emit && count > 0, "sat_encode_impl: the one-pass writer takes batches of aligned RGB0 frames");
     f360::KernelSpan span(ctx, f360::kSatWriteFuse, prof, (int)frames, stream);
-    launch_write_fuse(ctx, a, eb,
+    launch_write_fuse(ctx, stream, a, eb,
                       dim3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock, frames),
                       *band_fuse);
   } else {
@@ -793,13 +792,14 @@ extern "C" int f360_sat_encode_batch(f360_ctx *ctx, int count, uint32_t *const *
                              prof != 0);
     }
   }
-  for (int k = 0; k < count; k += per_launch) {
-    const int n = std::min(count - k, per_launch);
-    const int st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr,
-                                         nullptr, n, sat_dev + k, src_dev + k, prof);
-    if (st != F360_OK) return st;
-  }
-  return F360_OK;
+  F360_BIND_DEVICE(ctx);
+  return f360::sat_pipelined_groups(
+      ctx, width, height, false, (count + per_launch - 1) / per_launch, std::min(per_launch, count),
+      [&](int g, const f360::SatLaunch &where) {
+        const int k = g * per_launch, n = std::min(count - k, per_launch);
+        return f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr, nullptr,
+                                     n, sat_dev + k, src_dev + k, prof, nullptr, nullptr, &where);
+      });
 }
 
 extern "C" int f360_sat_encode_yuv420p_batch(f360_ctx *ctx, int count, uint32_t *const *sat_dev,
@@ -840,13 +840,14 @@ extern "C" int f360_sat_encode_yuv420p_batch(f360_ctx *ctx, int count, uint32_t 
                              prof != 0);
     }
   }
-  for (int k = 0; k < count; k += per_launch) {
-    const int n = std::min(count - k, per_launch);
-    const int st = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, 0, nullptr, nullptr,
-                                         n, sat_dev + k, nullptr, prof, planes.data() + k);
-    if (st != F360_OK) return st;
-  }
-  return F360_OK;
+  F360_BIND_DEVICE(ctx);
+  return f360::sat_pipelined_groups(
+      ctx, width, height, true, (count + per_launch - 1) / per_launch, std::min(per_launch, count),
+      [&](int g, const f360::SatLaunch &where) {
+        const int k = g * per_launch, n = std::min(count - k, per_launch);
+        return f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, 0, nullptr, nullptr, n,
+                                     sat_dev + k, nullptr, prof, planes.data() + k, nullptr, &where);
+      });
 }
 
 extern "C" int f360_sat_encode_yuv420p(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *y_dev,
