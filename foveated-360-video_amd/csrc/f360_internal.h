@@ -189,7 +189,7 @@ struct f360_ctx {
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos)
   int opt_gnomonic_guard = 1;  // "gnomonic.guard": texel indices from a cheap float evaluation wherever its error bound decides them, the exact chain for the others (64 at a time)
   int opt_fuse_walk = 1;       // "fuse.walk": f360_satdec_encode_sample_frames samples inside the read-once encoder's pass wherever it applies; 0 = always the two calls
-  int opt_fuse_band = 1;       // "fuse.band": f360_satdec_encode_sample_frames calls too small for the read-once encoder sample inside the three-kernel encoder's table writer (sat_write_fuse_kernel); 0 = the two calls
+  int opt_fuse_band = 1;       // "fuse.band": f360_satdec_encode_sample_frames calls too small for the read-once encoder sample inside the three-kernel encoder's table writer (sat_write_fuse_kernel): 1 = from two frames per call on (where the launch groups pipeline over the side stream; a single frame is faster as the two calls, profiles/round5_band_one_pass.txt), 2 = always, 0 = never (the two calls)
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
@@ -356,8 +356,8 @@ int side_stream(f360_ctx *ctx);
 
 // The same for calls the read-once encoder does not take (1 .. 22 8K frames): the three-kernel
 // encoder with its table writer in one-pass form (sat_band_fuse.hip); RGB0 frames.
-bool sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int height, int linesize,
-                                    int out_w, int out_h, int dst_linesize);
+bool sat_encode_sample_band_applies(const f360_ctx *ctx, int count, int width, int height,
+                                    int linesize, int out_w, int out_h, int dst_linesize);
 int sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats,
                            const uint8_t *const *srcs, int width, int height, int linesize,
                            const SatFuse &fuse, bool prof);

@@ -553,9 +553,9 @@ static size_t band_plan_lds_bytes(int height, int out_w, int out_h) {
 static size_t band_plan_lds_bytes(int width, int height, int out_w, int out_h) {
   return band_plan_lds_bytes(height, out_w, out_h) + (size_t)((width + kStripPx - 1) / kStripPx) * 1024;
 }
-bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int width, int height,
+bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int count, int width, int height,
                                           int linesize, int out_w, int out_h, int dst_linesize) {
-  return ctx->opt_fuse_band != 0 && linesize / width == 4 && linesize % 16 == 0 &&
+  return (ctx->opt_fuse_band == 2 || (ctx->opt_fuse_band == 1 && count >= 2)) && linesize / width == 4 && linesize % 16 == 0 &&
          width % 4 == 0 && width <= f360::kMaxDim &&
          (size_t)width * height * 3 < ((size_t)1 << 31) && out_w < 65536 && out_h < 65536 &&
          (width + kStripPx - 1) / kStripPx <= kFixCols / 4 && dst_linesize % 4 == 0 &&

@@ -1302,7 +1302,7 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
                                                      source_linesize, target_width, target_height,
                                                      target_linesize, planes);
   const bool bands = !walks && !planes && sats_dev &&
-                     f360::sat_encode_sample_band_applies(ctx, source_width, source_height,
+                     f360::sat_encode_sample_band_applies(ctx, count, source_width, source_height,
                                                           source_linesize, target_width,
                                                           target_height, target_linesize);
   bool one_pass = walks || bands;

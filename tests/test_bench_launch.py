@@ -34,7 +34,10 @@ def test_single_gpu_plan_is_the_plain_command():
         "two calls inside the library"
     # one frame per call: the reference's pair unless the one-pass call is asked for
     assert dry("--frames-per-call", "1")["ranks"][0]["one_pass"] is False
-    assert dry("--frames-per-call", "1", "--one-pass", "on")["ranks"][0]["one_pass"].startswith("band writer")
+    assert dry("--frames-per-call", "1", "--one-pass", "on")["ranks"][0]["one_pass"] == \
+        "two calls inside the library"   # (a single frame is faster as the two calls)
+    assert dry("--frames-per-call", "1", "--one-pass", "on", "--opt",
+               "fuse.band=2")["ranks"][0]["one_pass"].startswith("band writer")
     assert plan["launch"][1:] == [BENCH]          # no launcher around N = 1
 
 

@@ -38,12 +38,21 @@ def test_band_one_pass_matches_oracle(f360, gpu_ctx, oracle, w, h):
 
 
 def test_band_one_pass_one_frame_per_call(f360, gpu_ctx, oracle):
-    """The offline tool's shape: one frame, one gaze, one call -- for every gaze of the list."""
-    for k, g in enumerate(GAZES):
-        bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(f360, gpu_ctx, oracle, 1920, 1080, [g],
-                                                              seed=40 + k))
-        assert bad == [], g
-        assert "sat_write_fuse_kernel" in kernels
+    """The offline tool's shape: one frame, one gaze, one call -- for every gaze of the list.  By
+    default such a call is the two calls (faster for a single frame); "fuse.band" 2 sends it
+    through the band writer, and both must leave the oracle's bytes."""
+    bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(f360, gpu_ctx, oracle, 1920, 1080, [GAZES[3]]),
+                                    calls=2)
+    assert bad == [] and "sat_write_fuse_kernel" not in kernels and "sample_rect_kernel" in kernels
+    gpu_ctx.set_option("fuse.band", 2)
+    try:
+        for k, g in enumerate(GAZES):
+            bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(f360, gpu_ctx, oracle, 1920, 1080, [g],
+                                                                  seed=40 + k))
+            assert bad == [], g
+            assert "sat_write_fuse_kernel" in kernels
+    finally:
+        gpu_ctx.set_option("fuse.band", 1)
 
 
 def test_band_one_pass_special_frames(f360, gpu_ctx, oracle):
@@ -164,9 +173,13 @@ def test_band_one_pass_8k_against_the_oracle(f360, gpu_ctx, oracle, n):
         b.fill(0x5A)
     gpu_ctx.profile_reset()
     gpu_ctx.profile_arm(1)
-    dec.EncodeSampleFramesGPU([b.ptr for b in reds], rw, rh, 4 * rw, [b.ptr for b in sats],
-                              [b.ptr for b in srcs], w, h, 4 * w, gazes)
-    gpu_ctx.finish()
+    gpu_ctx.set_option("fuse.band", 2)  # (n == 1 too)
+    try:
+        dec.EncodeSampleFramesGPU([b.ptr for b in reds], rw, rh, 4 * rw, [b.ptr for b in sats],
+                                  [b.ptr for b in srcs], w, h, 4 * w, gazes)
+        gpu_ctx.finish()
+    finally:
+        gpu_ctx.set_option("fuse.band", 1)
     assert "sat_write_fuse_kernel" in gpu_ctx.profile_read()
     for k in range(n):
         want_sat = oracle.sat_encode(frames[k].reshape(-1), w, h, 4 * w)
