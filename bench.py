@@ -551,8 +551,11 @@ def main():
             return frames[k].cpu().numpy().reshape(-1)
 
         def pick(cands):
+            # the first frame and the one nearest a strip boundary -- two DIFFERENT frames where
+            # there are two (frame 0's Lissajous gaze is the centre, itself on a boundary at 8K)
             cands = sorted(cands)
-            return sorted({cands[0], min(cands, key=boundary_distance)})
+            rest = [k for k in cands if k != cands[0]]
+            return sorted({cands[0]} | ({min(rest, key=boundary_distance)} if rest else set()))
         red_frames = pick(range(B))
         held = {f_: t_ for t_, f_ in table_holds.items()}
         tab_frames = pick(held.keys()) if held else []

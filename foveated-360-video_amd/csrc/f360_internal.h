@@ -175,6 +175,7 @@ struct f360_ctx {
   int opt_batch_mb = 180;      // "sat.batch_mb": source bytes (MB) a batched encoder launch may cover
   int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows
   int opt_walk_units = 690;    // "sat.walk_units": (frame, strip) units a batch needs before sat.walk = -1 takes the read-once encoder (23 frames at 8K: a launch takes at least its 480 serial batches of ~3.5 us whatever its frame count, so below ~22 frames the three kernels' 101 us per frame win; profiles/round4_few_frames.txt)
+  int opt_pool_mb = 0;         // "sat.pool_mb": most device memory (MB) f360_sat_tables_alloc may hold at any time while it draws, scratch frames included; 0 = a third of what is free when the call starts (never less than the tables asked for plus one group)
   int opt_walk_frames = 0;     // "sat.walk_frames": most frames one read-once launch takes (1..64); 0 = about 1024 strip owners, one per SIMD
   int opt_interp_staged = 1;   // "interp.staged": the un-warp computes the vertical lerps once per reduced column (wave-private LDS) instead of per output pixel
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
@@ -209,7 +210,7 @@ struct f360_ctx {
   // call is still "enqueue on one in-order stream".
   hipStream_t side = nullptr;
   hipEvent_t side_fork = nullptr, side_join = nullptr;
-  int opt_pipeline = 1;  // "sat.pipeline": batched calls on the three-kernel encoder use the side stream (0 = one stream)
+  int opt_pipeline = 1;  // "sat.pipeline": batched calls on the three-kernel encoder alternate their launch groups between the context's stream and the side stream (0 = one stream).  (Reducers + carry passes on one stream and writers on the other, tied by an event pair per group, was slower than one stream: profiles/round5_band_one_pass.txt)
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;
   std::vector<f360::ProfSpan> prof_pending;

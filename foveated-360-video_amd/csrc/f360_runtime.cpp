@@ -292,6 +292,7 @@ static const OptionSlot kOptions[] = {
     {"fuse.walk", &f360_ctx::opt_fuse_walk},
     {"fuse.band", &f360_ctx::opt_fuse_band},
     {"sat.pipeline", &f360_ctx::opt_pipeline},
+    {"sat.pool_mb", &f360_ctx::opt_pool_mb},
     {"debug.fuse_force", &f360_ctx::opt_fuse_force},
     {"gnomonic.table", &f360_ctx::opt_gnomonic_table},
     {"gnomonic.guard", &f360_ctx::opt_gnomonic_guard},

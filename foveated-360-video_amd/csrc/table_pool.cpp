@@ -10,11 +10,18 @@ using namespace f360::sat;
 // A launch of sat_walk_kernel writes `group` tables (32 at 8K) at the same time, and the rate at
 // which this device takes those writes depends on what backs the tables: 5.5 to 7 TB/s for the
 // write pattern alone, in two clusters, by ALLOCATION -- not by address, pitch, row phase or
-// allocation API (profiles/round4_table_placement.txt, tools/frontbench).  User space can only
-// measure it.  So the pool draws groups: every group allocated while all earlier ones are still
-// held (so that it is backed by other memory), alternately as one allocation per table and as one
-// slab, one encode launch of scratch frames timed into each (the second of two), the fastest
-// ones kept, the rest given back.  Calls too small for the read-once encoder get plain allocations.
+// allocation API (profiles/round4_table_placement.txt, tools/frontbench; round 5's experiment on
+// the cause: profiles/round5_table_pool.txt).  User space can only measure it.  So the pool
+// draws groups -- alternately one allocation per table and one slab -- times one encode launch
+// of scratch frames into each (the second of two), keeps the fastest and gives the rest back.
+// A new group is drawn while earlier ones are still held, so that it is backed by other memory
+// than the ones already seen; how much may be held at once is BOUNDED ("sat.pool_mb", default a
+// third of the device memory that is free when the call starts, never less than the tables the
+// caller asked for plus one group): when a new draw would exceed the bound, the slowest group held
+// beyond those worth keeping is given back first.  Drawing stops when enough groups lie within
+// 4 % of the fastest seen (and a few more than needed have been looked at), after `nlaunch + 12`
+// draws, or when memory runs out.  Calls too small for the read-once encoder get plain
+// allocations.
 struct f360_table_pool {
   std::vector<void *> allocs;   // what f360_sat_tables_free gives back
   std::string report;
@@ -34,18 +41,17 @@ extern "C" int f360_sat_tables_alloc(f360_ctx *ctx, int width, int height, int c
     delete pool;
     return st;
   };
-  const int strips = (width + kStripPx - 1) / kStripPx;
   // (the conditions under which f360_sat_encode_batch takes the read-once encoder)
   const bool walks = walk_wanted(ctx, count, width) && width % 4 == 0 &&
                      (size_t)width * height * 3 < ((size_t)1 << 31);
-  char line[160];
+  char line[200];
   if (!walks) {
     for (int k = 0; k < count; ++k) {
       void *p = nullptr;
       if (hipMalloc(&p, tb) != hipSuccess) {
         (void)hipGetLastError();
         f360::set_error("f360_sat_tables_alloc: out of device memory");
-        return fail(F360_ERR_HIP);
+        return fail(F360_ERR_OOM);
       }
       pool->allocs.push_back(p);
       tables_out[k] = static_cast<uint32_t *>(p);
@@ -54,42 +60,64 @@ extern "C" int f360_sat_tables_alloc(f360_ctx *ctx, int width, int height, int c
     *pool_out = pool;
     return F360_OK;
   }
-  int max_frames = ctx->opt_walk_frames > 0 ? ctx->opt_walk_frames : std::max(1024 / strips, 1);
-  max_frames = std::min(max_frames, kWalkFrames);
-  const int nlaunch = (count + max_frames - 1) / max_frames;
-  const int group = (count + nlaunch - 1) / nlaunch;
+  const int group = walk_frames_per_launch(ctx, count, width);
+  const int nlaunch = (count + group - 1) / group;
+  const size_t group_bytes = tb * (size_t)group;
+  // the bound on what the pool holds at any time, scratch frames included
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    free_b = total_b = 0;
+  }
+  const size_t fb = (size_t)width * height * 4;
+  const size_t needed = group_bytes * (size_t)(nlaunch + 1) + fb * (size_t)group;
+  size_t cap = ctx->opt_pool_mb > 0 ? (size_t)ctx->opt_pool_mb << 20 : free_b / 3;
+  cap = std::max(cap, needed);
+  const int hold_max = (int)std::max<size_t>((cap - fb * (size_t)group) / group_bytes, (size_t)(nlaunch + 1));
   struct Draw {
     float us = 0;
     bool slab = false;
     std::vector<void *> allocs;
     std::vector<uint32_t *> tabs;
   };
-  std::vector<Draw> draws;
+  std::vector<Draw> held;  // groups currently allocated
   auto drop = [&](Draw &d) {
     for (void *p : d.allocs) (void)hipFree(p);
     d.allocs.clear();
   };
   void *zero = nullptr;
-  const size_t fb = (size_t)width * height * 4;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int st = F360_OK;
   // (sources: `group` frames' worth of scratch, contents irrelevant -- distinct frames, so that
   // the timed launch reads from memory as a real one does)
   if (hipMalloc(&zero, fb * group) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
-      hipEventCreate(&e1) != hipSuccess)
-    st = F360_ERR_HIP;
-  const float good_us = 80.5f * (float)((double)width * height / (7680.0 * 3840.0));
+      hipEventCreate(&e1) != hipSuccess) {
+    (void)hipGetLastError();
+    f360::set_error("f360_sat_tables_alloc: cannot allocate the scratch frames (%zu bytes) or "
+                    "the timing events", fb * (size_t)group);
+    st = F360_ERR_OOM;
+  }
   std::vector<const uint8_t *> srcs((size_t)group);
   for (int k = 0; k < group; ++k) srcs[(size_t)k] = static_cast<const uint8_t *>(zero) + (size_t)k * fb;
-  // (up to nlaunch + 12 draws: on the boxes where most allocations draw badly -- 7 of 8 at
-  // 86-94 us seen -- eight draws left a 1-in-4 chance of keeping a mediocre group; a draw is
-  // 11 GB at 8K, held until the choice is made, and running out of memory just ends the drawing)
-  for (int i = 0; st == F360_OK && i < nlaunch + 12; ++i) {
+  std::vector<float> seen;  // every draw's time, for the report and the stopping rule
+  size_t held_peak = 0;
+  int draws = 0, returned_early = 0;
+  for (; st == F360_OK && draws < nlaunch + 12; ++draws) {
+    // room for one more group?  give the slowest one back first (never one of the `nlaunch`
+    // fastest: those are the ones the caller gets)
+    if ((int)held.size() >= hold_max) {
+      size_t worst = 0;
+      for (size_t k = 1; k < held.size(); ++k)
+        if (held[k].us > held[worst].us) worst = k;
+      drop(held[worst]);
+      held.erase(held.begin() + (long)worst);
+      ++returned_early;
+    }
     Draw d;
-    d.slab = i % 2 == 1;
+    d.slab = draws % 2 == 1;
     if (d.slab) {
       void *p = nullptr;
-      if (hipMalloc(&p, tb * group) != hipSuccess) {
+      if (hipMalloc(&p, group_bytes) != hipSuccess) {
         (void)hipGetLastError();
         break;  // out of memory: make do with what has been drawn
       }
@@ -124,38 +152,56 @@ extern "C" int f360_sat_tables_alloc(f360_ctx *ctx, int width, int height, int c
       if (st == F360_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) st = F360_ERR_HIP;
       d.us = 1e3f * ms / (float)group;
     }
-    snprintf(line, sizeof line, "%s%s %.1f", draws.empty() ? "" : ", ", d.slab ? "slab" : "separate",
-             d.us);
+    if (st != F360_OK) {
+      (void)hipGetLastError();
+      f360::set_error("f360_sat_tables_alloc: timing a launch into a drawn group failed");
+      drop(d);
+      break;
+    }
+    snprintf(line, sizeof line, "%s%s %.1f", seen.empty() ? "" : ", ", d.slab ? "slab" : "separate", d.us);
     pool->report += line;
-    draws.push_back(std::move(d));
+    seen.push_back(d.us);
+    held.push_back(std::move(d));
+    held_peak = std::max(held_peak, held.size() * group_bytes + fb * (size_t)group);
+    // Enough good ones?  "Good" is relative to the fastest draw seen (the two clusters lie 10-15 %
+    // apart), so the rule holds on any device and clock; a fastest draw can only be recognised as
+    // such after a few more than needed have been looked at.
+    const float best = *std::min_element(seen.begin(), seen.end());
     int good = 0;
-    for (const Draw &x : draws) good += x.us <= good_us;
-    if (good >= nlaunch) break;
+    for (const Draw &x : held) good += x.us <= best * 1.04f;
+    if (good >= nlaunch && draws + 1 >= nlaunch + 3) {
+      ++draws;
+      break;
+    }
   }
   if (zero) (void)hipFree(zero);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
-  if (st != F360_OK || (int)draws.size() < nlaunch) {
-    for (Draw &d : draws) drop(d);
+  if (st != F360_OK || (int)held.size() < nlaunch) {
+    for (Draw &d : held) drop(d);
     if (st == F360_OK) {
-      f360::set_error("f360_sat_tables_alloc: out of device memory");
-      st = F360_ERR_HIP;
+      f360::set_error("f360_sat_tables_alloc: out of device memory (%d of %d groups of %zu bytes)",
+                      (int)held.size(), nlaunch, group_bytes);
+      st = F360_ERR_OOM;
     }
     return fail(st);
   }
-  std::sort(draws.begin(), draws.end(), [](const Draw &a, const Draw &b) { return a.us < b.us; });
-  pool->report = "us per frame of one launch into each drawn group of " + std::to_string(group) +
-                 " tables: " + pool->report + "; kept:";
+  std::sort(held.begin(), held.end(), [](const Draw &a, const Draw &b) { return a.us < b.us; });
+  snprintf(line, sizeof line,
+           "us per frame of one launch into each of %d drawn groups of %d tables (at most %d held "
+           "at once: %.1f of %.1f GB allowed, %d given back before the end): ",
+           draws, group, hold_max, (double)held_peak / 1e9, (double)cap / 1e9, returned_early);
+  pool->report = std::string(line) + pool->report + "; kept:";
   int k = 0;
-  for (int g = 0; g < (int)draws.size(); ++g) {
+  for (int g = 0; g < (int)held.size(); ++g) {
     if (g < nlaunch) {
-      snprintf(line, sizeof line, " %s %.1f", draws[g].slab ? "slab" : "separate", draws[g].us);
+      snprintf(line, sizeof line, " %s %.1f", held[g].slab ? "slab" : "separate", held[g].us);
       pool->report += line;
-      for (void *p : draws[g].allocs) pool->allocs.push_back(p);
-      for (uint32_t *t : draws[g].tabs)
+      for (void *p : held[g].allocs) pool->allocs.push_back(p);
+      for (uint32_t *t : held[g].tabs)
         if (k < count) tables_out[k++] = t;
     } else {
-      drop(draws[g]);
+      drop(held[g]);
     }
   }
   *pool_out = pool;

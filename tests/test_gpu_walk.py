@@ -264,6 +264,33 @@ def test_table_pool_allocates_usable_tables(f360, oracle):
             pool.free()   # idempotent
 
 
+def test_table_pool_respects_its_memory_bound(f360, oracle):
+    """"sat.pool_mb": the pool never holds more than the bound while it draws (the report says how
+    much it held at most) -- here room for the tables asked for plus ONE group, so every further
+    draw first gives the slowest group back -- and what it keeps is still right."""
+    import re
+    w, h, n = 2304, 256, 128          # 9 strips, at most 64 frames per launch: two groups of 64
+    with f360.Context(0) as ctx:
+        enc = f360.SATEncoder(ctx)
+        group_mb = 64 * w * h * 12 / 2 ** 20
+        ctx.set_option("sat.pool_mb", int(3 * group_mb + 64 * w * h * 4 / 2 ** 20 + 2))
+        pool = enc.AllocateTables(w, h, n)
+        m = re.search(r"at most (\d+) held at once: ([0-9.]+) of ([0-9.]+) GB allowed, (\d+) given back", pool.report)
+        assert m, pool.report
+        assert int(m.group(1)) == 3 and float(m.group(2)) <= float(m.group(3)) + 1e-3, pool.report
+        assert int(m.group(4)) >= 1, pool.report      # (at least five draws are looked at)
+        assert len(set(pool.ptrs)) == n
+        frames = [oracle.lcg_frame(w, h, 900 + k) for k in (0, 1)]
+        srcs = [ctx.upload(f) for f in frames]
+        enc.EncodeFramesGPU(pool.ptrs, [srcs[k % 2].ptr for k in range(n)], w, h, 4 * w)
+        for k in (0, 63, 64, n - 1):
+            assert np.array_equal(pool.read_table(k, (h, w, 3)), oracle.sat_encode(frames[k % 2], w, h, 4 * w))
+        for b in srcs:
+            b.free()
+        pool.free()
+        ctx.set_option("sat.pool_mb", 0)
+
+
 def test_walker_refuses_to_allocate_under_stream_capture(f360, oracle):
     """The first read-once call on a context allocates its hand-off buffers (and a larger call
     re-allocates them): illegal while the stream is being captured, so it is refused with a

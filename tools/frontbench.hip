@@ -185,6 +185,67 @@ int vmm_scan() {
   return 0;
 }
 
+// Round 5: is it the PHYSICAL interleave of what backs the tables?  32 tables of `chunk`-byte
+// handles each; the handles of a table are (a) created and mapped in order, (b) created in order and
+// mapped at SHUFFLED offsets of the table's address range, (c) created round-robin over the tables
+// (table 0's first chunk, table 1's first chunk, ...: physically interleaved across tables) and
+// mapped in order.  Same virtual layout, same handle size, same driver path in all three -- only the
+// virtual-to-physical order differs.
+static int vmm_tables(Tabs &t, size_t chunk, int how, unsigned seed) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = 0;
+  size_t gran = 0;
+  CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+  chunk = (chunk + gran - 1) / gran * gran;
+  const size_t n = (TAB + chunk - 1) / chunk, total = n * chunk;
+  std::vector<std::vector<hipMemGenericAllocationHandle_t>> h(NF, std::vector<hipMemGenericAllocationHandle_t>(n));
+  if (how == 2) {
+    for (size_t k = 0; k < n; ++k)
+      for (int f = 0; f < NF; ++f) CK(hipMemCreate(&h[f][k], chunk, &prop, 0));
+  } else {
+    for (int f = 0; f < NF; ++f)
+      for (size_t k = 0; k < n; ++k) CK(hipMemCreate(&h[f][k], chunk, &prop, 0));
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  for (int f = 0; f < NF; ++f) {
+    void *va = nullptr;
+    CK(hipMemAddressReserve(&va, total, 0, nullptr, 0));
+    std::vector<size_t> slot(n);
+    for (size_t k = 0; k < n; ++k) slot[k] = k;
+    if (how == 1)
+      for (size_t k = n - 1; k > 0; --k) {  // Fisher-Yates with an LCG
+        seed = seed * 1664525u + 1013904223u;
+        std::swap(slot[k], slot[(seed >> 8) % (k + 1)]);
+      }
+    for (size_t k = 0; k < n; ++k) CK(hipMemMap((char *)va + slot[k] * chunk, chunk, 0, h[f][k], 0));
+    CK(hipMemSetAccess(va, total, &acc, 1));
+    t.p[f] = (uint8_t *)va;
+  }
+  return 0;
+}
+
+int shuffle_scan() {
+  Tabs sep;
+  for (int f = 0; f < NF; ++f) CK(hipMalloc(&sep.p[f], TAB));
+  run<0>(sep, NF, "hipMalloc, one allocation per table");
+  const char *names[3] = {"in order", "shuffled inside each table", "created round-robin over the tables"};
+  for (int rep = 0; rep < 2; ++rep)
+    for (size_t chunk : {(size_t)2 << 20, (size_t)8 << 20, (size_t)32 << 20})
+      for (int how = 0; how < 3; ++how) {
+        Tabs t;
+        if (vmm_tables(t, chunk, how, 12345u + rep)) return 1;
+        char what[112];
+        snprintf(what, sizeof what, "%zu MiB handles, %s", chunk >> 20, names[how]);
+        run<0>(t, NF, what);
+      }
+  run<0>(sep, NF, "hipMalloc, one allocation per table (again)");
+  return 0;
+}
+
 int pool_scan() {
   // ONE pool; tables carved at different base offsets and pitches inside it: the same physical
   // backing throughout, so whatever differs is decided by the addresses alone
@@ -210,6 +271,7 @@ int main(int argc, char **argv) {
   if (argc > 1 && argv[1][0] == 'p') return pool_scan();
   if (argc > 1 && argv[1][0] == 'b') return per_bo_scan();
   if (argc > 1 && argv[1][0] == 'v') return vmm_scan();
+  if (argc > 1 && argv[1][0] == 's') return shuffle_scan();
   const bool scan = argc > 1;
   // A: one allocation per table
   Tabs sep;
