@@ -525,7 +525,7 @@ def main():
     recoveries = 0
     for c in ctxs:
         c.finish()
-        recoveries += c.debug_walk_recoveries()
+        recoveries += c.handoff_recoveries()
 
     # ---- what the timed calls wrote, against the CPU oracle (VERDICT r4 missing #3) ----------
     # Reduced frames: frame 0 and the frame whose gaze lies nearest a strip boundary (a multiple

@@ -164,6 +164,7 @@ _SIGNATURES = {
     "f360_ctx_profile_frames": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "f360_debug_walk_stats": (c_int, [c_void_p, c_void_p, c_int]),
     "f360_debug_walk_recoveries": (c_int, [c_void_p, POINTER(ctypes.c_uint)]),
+    "f360_ctx_handoff_recoveries": (c_int, [c_void_p, POINTER(ctypes.c_uint)]),
     "f360_debug_gn_fast_sweep": (c_int, [c_void_p, c_int, ctypes.c_ulonglong, c_void_p, c_void_p]),
     "f360_debug_gnomonic_worklist": (c_int, [c_void_p, c_void_p]),
     "f360_ctx_profile_reset": (c_int, [c_void_p]),
@@ -306,6 +307,13 @@ class Context:
         if n < 0:
             _check(n)
         return out[:n]
+
+    def handoff_recoveries(self) -> int:
+        """f360_ctx_handoff_recoveries: strips of read-once launches that finished without their
+        hand-off since the last call (the results are exact either way; time was lost)."""
+        c = ctypes.c_uint(0)
+        _check(lib().f360_ctx_handoff_recoveries(self._h, byref(c)))
+        return c.value
 
     def debug_walk_recoveries(self) -> int:
         """Strips of read-once encoder launches that gave up waiting for their hand-off and

@@ -192,6 +192,10 @@ extern "C" int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int
 // Strips of read-once launches that gave up waiting for their hand-off and finished alone (the
 // tables are right either way) since the last call of this function; blocks until the stream
 // has drained.
+extern "C" int f360_debug_walk_recoveries(f360_ctx *ctx, unsigned *count_out);
+extern "C" int f360_ctx_handoff_recoveries(f360_ctx *ctx, unsigned *count_out) {
+  return f360_debug_walk_recoveries(ctx, count_out);
+}
 extern "C" int f360_debug_walk_recoveries(f360_ctx *ctx, unsigned *count_out) {
   F360_REQUIRE(ctx && count_out, "f360_debug_walk_recoveries: bad argument");
   F360_BIND_DEVICE(ctx);

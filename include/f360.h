@@ -432,6 +432,10 @@ int f360_debug_walk_stats(f360_ctx *ctx, unsigned long long *out, int max_units)
  * alone -- it recomputes the row sums to its left from the source -- so the tables are exact
  * either way; a non-zero count only says that time was lost.  Blocks until the stream is idle. */
 int f360_debug_walk_recoveries(f360_ctx *ctx, unsigned *count_out);
+/* The same count under a name of its own for production callers (a monitoring loop polls it
+ * beside f360_sync: a hand-off that timed out costs time, never a result, and f360_sync does not
+ * report it).  Reads and clears the counter; blocks until the stream is idle. */
+int f360_ctx_handoff_recoveries(f360_ctx *ctx, unsigned *count_out);
 /* Test entries for the index-guarded gnomonic remap (csrc/gn_fast_math.h, option
  * "gnomonic.guard").  _sweep: the largest absolute error of a fast float core against double
  * precision over a device-side sweep -- kind 0: asin over every float in [-1, 1] (n ignored);

@@ -91,6 +91,57 @@ def all_loops(ins):
             if tgt is not None and tgt <= a and tgt in index]
 
 
+def regs_of(operand):
+    """Register numbers an operand token names: 's[10:17]' -> {('s', 10) .. ('s', 17)}."""
+    m = re.match(r"^([sv])\[(\d+):(\d+)\]$", operand)
+    if m:
+        return {(m.group(1), k) for k in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r"^([sv])(\d+)$", operand)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def inflight_violations(ins):
+    """LDS / scalar-memory loads whose destination registers are touched before a wait has covered
+    them (the strip walker issues some of its loads and their waits from SEPARATE asm
+    statements -- the plan words' s_load_dwordx8, the first look at a mailbox word -- so nothing
+    but this check stops a future compiler from copying or spilling a register that is still in
+    flight).  Straight-line model: loads enter a queue in program order; `s_waitcnt lgkmcnt(N)`
+    retires all but the youngest N when only LDS operations are pending (they return in order) and
+    everything when N is 0 (scalar loads return out of order, so any other count retires none of
+    them); a branch target or a branch empties the queue conservatively (the compiler's and the asm
+    statements' own waits sit in front of those).  Returns [(load text, offending text)]."""
+    pending, bad = [], []   # pending: (kind 'lds' | 'smem', regs, text)
+    targets = {t for _, _, t in ins if t is not None}
+    for addr, text, tgt in ins:
+        if addr in targets or tgt is not None:
+            pending = []
+        ops = [o.strip() for o in re.split(r"[ ,]+", text)[1:]]
+        if text.startswith("s_waitcnt"):
+            m = re.search(r"lgkmcnt\((\d+)\)", text)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    pending = []
+                elif all(k == "lds" for k, _, _ in pending):
+                    pending = pending[-n:] if n < len(pending) else pending
+            continue
+        touched = set()
+        for o in ops:
+            touched |= regs_of(o)
+        for kind, regs, ltext in pending:
+            if regs & touched:
+                bad.append((ltext, text))
+        if text.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle")) and ops:
+            pending.append(("lds", regs_of(ops[0]), text))
+        elif text.startswith(("s_load_", "s_buffer_load")) and ops:
+            pending.append(("smem", regs_of(ops[0]), text))
+        elif text.startswith(("ds_write", "ds_add", "ds_cmpst", "ds_wrxchg", "ds_max", "ds_min", "ds_or", "ds_and")):
+            pending.append(("lds", set(), text))   # (counted by lgkmcnt, no destination)
+        elif text.startswith("s_memtime") or text.startswith("s_memrealtime"):
+            pending.append(("smem", regs_of(ops[0]) if ops else set(), text))
+    return bad
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     strict = "--strict" in sys.argv[1:]
@@ -213,6 +264,10 @@ def main():
                 # -- the pixel stores are hidden from the compiler, and any vmcnt wait there
                 # also waits for the stores of the row before (it cost 800 cycles per row when a
                 # plan word was read with a vector load)
+                if "sat_walk" in name or "sat_write_fuse_kernel" in name:
+                    for ltext, utext in inflight_violations(ins)[:3]:
+                        errors.append(f"{name}: `{utext}` touches a register `{ltext}` still has "
+                                      f"in flight")
                 if "sat_walk" in name and "Lb1E" in name:
                     seen.add("one-pass walker")
                     px = [[t for _, t, _ in lp] for lp in all_loops(ins)]

@@ -45,3 +45,31 @@ def test_objdump_lookup_honours_rocm_path(tmp_path, monkeypatch):
     (fake / "llvm-objdump").write_text("#!/bin/sh\n")
     monkeypatch.setenv("ROCM_PATH", str(tmp_path))
     assert check_isa.find_objdump() == str(fake / "llvm-objdump")
+
+
+def test_inflight_register_rule():
+    """scripts/check_isa.py inflight_violations: a register a load still has in flight must not be
+    read or written before a wait covers it (the strip walker issues loads and their waits from
+    separate asm statements)."""
+    import check_isa
+
+    def prog(*texts):
+        return [(4 * k, t, None) for k, t in enumerate(texts)]
+    # the walker's plan words: load, unrelated work, wait, use -- fine
+    assert check_isa.inflight_violations(prog(
+        "s_load_dwordx8 s[8:15], s[0:1], 0x0", "v_add_u32_e32 v1, v2, v3", "s_waitcnt lgkmcnt(0)",
+        "s_and_b32 s20, s9, 1")) == []
+    # a copy of one of the words before the wait -- caught
+    bad = check_isa.inflight_violations(prog(
+        "s_load_dwordx8 s[8:15], s[0:1], 0x0", "s_mov_b32 s20, s9", "s_waitcnt lgkmcnt(0)"))
+    assert len(bad) == 1 and "s_mov_b32" in bad[0][1]
+    # LDS returns in order: lgkmcnt(1) covers the older of two reads, not the younger
+    assert check_isa.inflight_violations(prog(
+        "ds_read_b32 v4, v0", "ds_read_b32 v5, v1", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v6, v4")) == []
+    bad = check_isa.inflight_violations(prog(
+        "ds_read_b32 v4, v0", "ds_read_b32 v5, v1", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v6, v5"))
+    assert len(bad) == 1
+    # a counted wait retires no scalar load (they return out of order)
+    bad = check_isa.inflight_violations(prog(
+        "s_load_dword s4, s[0:1], 0x0", "ds_read_b32 v5, v1", "s_waitcnt lgkmcnt(1)", "s_add_u32 s5, s4, 1"))
+    assert len(bad) == 1
