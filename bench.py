@@ -156,7 +156,7 @@ def one_pass_plan(args, frames_per_call):
         if o.get("fuse.walk", "1") != "0":
             return "strip walker (sat_walk_kernel<.., true>)"
     band = int(o.get("fuse.band", "1"))
-    if (band == 2 or (band == 1 and frames_per_call >= 2)) and args.source == "rgb0":
+    if (band == 2 or (band == 1 and frames_per_call >= 4)) and args.source == "rgb0":
         return "band writer (sat_write_fuse_kernel)"
     return "two calls inside the library"
 

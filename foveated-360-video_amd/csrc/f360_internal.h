@@ -190,7 +190,7 @@ struct f360_ctx {
   int opt_gnomonic_table = 1;  // "gnomonic.table": view-independent terms of the remap read from a per-geometry table: 0 none, 1 five planes (x, y, rho, sin, cos)
   int opt_gnomonic_guard = 1;  // "gnomonic.guard": texel indices from a cheap float evaluation wherever its error bound decides them, the exact chain for the others (64 at a time)
   int opt_fuse_walk = 1;       // "fuse.walk": f360_satdec_encode_sample_frames samples inside the read-once encoder's pass wherever it applies; 0 = always the two calls
-  int opt_fuse_band = 1;       // "fuse.band": f360_satdec_encode_sample_frames calls too small for the read-once encoder sample inside the three-kernel encoder's table writer (sat_write_fuse_kernel): 1 = from two frames per call on (where the launch groups pipeline over the side stream; a single frame is faster as the two calls, profiles/round5_band_one_pass.txt), 2 = always, 0 = never (the two calls)
+  int opt_fuse_band = 1;       // "fuse.band": f360_satdec_encode_sample_frames calls too small for the read-once encoder sample inside the three-kernel encoder's table writer (sat_write_fuse_kernel): 1 = from four frames per call on (where the launch groups, pipelined over the side stream, beat the two calls: +2 % at 4 frames of 8K, +8 % at 8-22; one and two frames are faster as the two calls, profiles/round5_band_one_pass.txt), 2 = always, 0 = never (the two calls)
   int opt_fov_piggyback = 1;   // "fov.piggyback": lattice maps of the fused path as extra workgroups of the reducer
   int opt_yuv_model = 1;       // "yuv.model": libswscale converter to reproduce, 0 C tables, 1 x86 MMX
   // "expand" debug views (expand.hip): per-geometry axis tables and the ordering keys of the
@@ -210,7 +210,7 @@ struct f360_ctx {
   // call is still "enqueue on one in-order stream".
   hipStream_t side = nullptr;
   hipEvent_t side_fork = nullptr, side_join = nullptr;
-  int opt_pipeline = 1;  // "sat.pipeline": batched calls on the three-kernel encoder alternate their launch groups between the context's stream and the side stream (0 = one stream).  (Reducers + carry passes on one stream and writers on the other, tied by an event pair per group, was slower than one stream: profiles/round5_band_one_pass.txt)
+  int opt_pipeline = 1;  // "sat.pipeline": batched calls on the three-kernel encoder alternate their launch groups between the context's stream and the side stream: 1 = the band writer's one pass only (+14 %; the plain three kernels gain nothing), 2 = every batched call, 0 = one stream.  (Reducers + carry passes on one stream and writers on the other, tied by an event pair per group, was slower than one stream: profiles/round5_band_one_pass.txt)
   // per-kernel HIP-event timing of sampled calls (f360_ctx_profile_arm/read)
   int prof_armed = 0;
   std::vector<f360::ProfSpan> prof_pending;
@@ -305,8 +305,10 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
 // `launch(g, where)` enqueues group g.
 template <class Launch>
 int sat_pipelined_groups(f360_ctx *ctx, int width, int height, bool planar, int ngroups,
-                         int group_frames, Launch &&launch) {
-  const bool pipelined = ctx->opt_pipeline != 0 && ngroups >= 2;
+                         int group_frames, bool one_pass, Launch &&launch) {
+  // (the plain three kernels gain nothing from it -- their writer is bandwidth-bound, and a
+  // reducer beside it takes what it gives -- so they stay on one stream unless "sat.pipeline" is 2)
+  const bool pipelined = (ctx->opt_pipeline == 2 || (ctx->opt_pipeline == 1 && one_pass)) && ngroups >= 2;
   int st = F360_OK;
   if (pipelined) {
     st = side_stream(ctx);

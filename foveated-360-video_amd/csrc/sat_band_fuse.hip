@@ -555,7 +555,7 @@ static size_t band_plan_lds_bytes(int width, int height, int out_w, int out_h) {
 }
 bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int count, int width, int height,
                                           int linesize, int out_w, int out_h, int dst_linesize) {
-  return (ctx->opt_fuse_band == 2 || (ctx->opt_fuse_band == 1 && count >= 2)) && linesize / width == 4 && linesize % 16 == 0 &&
+  return (ctx->opt_fuse_band == 2 || (ctx->opt_fuse_band == 1 && count >= 4)) && linesize / width == 4 && linesize % 16 == 0 &&
          width % 4 == 0 && width <= f360::kMaxDim &&
          (size_t)width * height * 3 < ((size_t)1 << 31) && out_w < 65536 && out_h < 65536 &&
          (width + kStripPx - 1) / kStripPx <= kFixCols / 4 && dst_linesize % 4 == 0 &&
@@ -634,7 +634,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
     // (launch groups alternate between the context's stream and its side stream, see
     // sat_pipelined_groups: forked after the plan kernel, joined before the fix-up)
     st = f360::sat_pipelined_groups(
-        ctx, width, height, false, (n + per_launch - 1) / per_launch, std::min(per_launch, n),
+        ctx, width, height, false, (n + per_launch - 1) / per_launch, std::min(per_launch, n), true,
         [&](int g, const f360::SatLaunch &where) {
           const int k0 = g * per_launch, m = std::min(n - k0, per_launch);
           bf.frame0 = k0;

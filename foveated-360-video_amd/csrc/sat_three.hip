@@ -619,7 +619,7 @@ extern "C" int f360_sat_encode_batch(f360_ctx *ctx, int count, uint32_t *const *
   }
   F360_BIND_DEVICE(ctx);
   return f360::sat_pipelined_groups(
-      ctx, width, height, false, (count + per_launch - 1) / per_launch, std::min(per_launch, count),
+      ctx, width, height, false, (count + per_launch - 1) / per_launch, std::min(per_launch, count), false,
       [&](int g, const f360::SatLaunch &where) {
         const int k = g * per_launch, n = std::min(count - k, per_launch);
         return f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr, nullptr,
@@ -667,7 +667,7 @@ extern "C" int f360_sat_encode_yuv420p_batch(f360_ctx *ctx, int count, uint32_t 
   }
   F360_BIND_DEVICE(ctx);
   return f360::sat_pipelined_groups(
-      ctx, width, height, true, (count + per_launch - 1) / per_launch, std::min(per_launch, count),
+      ctx, width, height, true, (count + per_launch - 1) / per_launch, std::min(per_launch, count), false,
       [&](int g, const f360::SatLaunch &where) {
         const int k = g * per_launch, n = std::min(count - k, per_launch);
         return f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, 0, nullptr, nullptr, n,

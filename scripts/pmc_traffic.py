@@ -3,7 +3,7 @@
 output directories) and stamps it with the hash of the kernel sources it was measured on:
 bench.py reports `roofline.traffic` only while that hash matches the tree it runs from.
 
-    python scripts/pmc_traffic.py <out.json> <pmc dir(s) with FETCH_SIZE> <pmc dir(s) with WRITE_SIZE> [yuv dirs...]
+    python scripts/pmc_traffic.py <out.json> <pmc dir(s) with FETCH_SIZE> <pmc dir(s) with WRITE_SIZE> [yuv fetch, yuv write [band fetch, band write]]
     (a "dir" may be several directories joined with ':' -- the default command's passes and the
     one-frame-per-call passes; the default command's passes with and without --one-pass)
     python scripts/pmc_traffic.py --hash          # the hash of the current csrc/
@@ -85,9 +85,9 @@ def main():
             doc.setdefault("sat_walk_kernel", {})[size + ":yuv420p:one_pass"] = int(
                 1024 * (2 * yf["sat_walk_kernel<3, 2, true>"] + yw["sat_walk_kernel<3, 2, true>"]) / 32)
             for kernel in ("walk_fuse_plan_kernel", "walk_fuse_fix_kernel"):
-                if kernel in yf and kernel in yw:
+                if kernel + "<0>" in yf and kernel + "<0>" in yw:
                     doc.setdefault(kernel, {})[size + ":yuv420p:one_pass"] = int(
-                        1024 * (yf[kernel] + yw[kernel]) / 32)
+                        1024 * (yf[kernel + "<0>"] + yw[kernel + "<0>"]) / 32)
         # planar source, x86 rounding model = 3
         for inst, kernel, fpl in (("sat_walk_kernel<3, 2, false>", "sat_walk_kernel", 32),
                                   ("sat_write_kernel<3, 1>", "sat_write_kernel", 1),
@@ -97,13 +97,26 @@ def main():
     # the default command's one-pass kernels (EncodeSampleFramesGPU): the strip walker with helper
     # waves, its row-plan kernel and the fix-up of the boxes that straddle two strips
     for inst, kernel, dbl in (("sat_walk_kernel<1, 2, true>", "sat_walk_kernel", 2),
-                              ("walk_fuse_plan_kernel", "walk_fuse_plan_kernel", 1),
-                              ("walk_fuse_fix_kernel", "walk_fuse_fix_kernel", 1)):
+                              ("walk_fuse_plan_kernel<0>", "walk_fuse_plan_kernel", 1),
+                              ("walk_fuse_fix_kernel<0>", "walk_fuse_fix_kernel", 1)):
         if inst in fetch and inst in write:
             e = doc.setdefault(kernel, {})
             e[size + ":one_pass"] = int(1024 * (dbl * fetch[inst] + write[inst]) / 32)
             e["_one_pass_fetch_kb"] = round(fetch[inst] / 32, 1)
             e["_one_pass_write_kb"] = round(write[inst] / 32, 1)
+    # the band writer's one pass (8 frames per call, one frame per launch of the three kernels; the
+    # plan kernel covers the call's 8 frames; the fix-up kernel is shared with the strip walker's
+    # one pass and is told apart by the frames of its launch -- see `means`)
+    if len(sys.argv) >= 8:
+        bf, bw = means(sys.argv[6], "FETCH_SIZE"), means(sys.argv[7], "WRITE_SIZE")
+        for inst, kernel, dbl, fpl in (("sat_write_fuse_kernel<1>", "sat_write_fuse_kernel", 2, 1),
+                                       ("band_fuse_plan_kernel", "walk_fuse_plan_kernel", 1, 8),
+                                       ("walk_fuse_fix_kernel<0>", "walk_fuse_fix_kernel", 1, 8)):
+            if inst in bf and inst in bw:
+                e = doc.setdefault(kernel, {})
+                e[size + ":band_one_pass"] = int(1024 * (dbl * bf[inst] + bw[inst]) / fpl)
+                e["_band_fetch_kb"] = round(bf[inst] / fpl, 1)
+                e["_band_write_kb"] = round(bw[inst] / fpl, 1)
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc))

@@ -59,9 +59,11 @@ def test_band_one_pass_special_frames(f360, gpu_ctx, oracle):
     """An all-255 frame (largest sums, boxes of 255 exactly), an all-zero one, padded targets."""
     w, h = 1536, 320
     frames = [np.full((h, 4 * w), 255, dtype=np.uint8), np.zeros((h, 4 * w), dtype=np.uint8),
-              oracle.lcg_frame(w, h, 9)]
-    assert _run(f360, gpu_ctx, oracle, w, h, [(0.5, 0.5), (0.1, 0.9), (0.8, 0.3)], frames=frames,
-                tpad=32, fill=0x3C) == []
+              oracle.lcg_frame(w, h, 9), oracle.lcg_frame(w, h, 10)]
+    bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(
+        f360, gpu_ctx, oracle, w, h, [(0.5, 0.5), (0.1, 0.9), (0.8, 0.3), (0.3, 0.2)], frames=frames,
+        tpad=32, fill=0x3C))
+    assert bad == [] and "sat_write_fuse_kernel" in kernels
 
 
 def test_band_one_pass_gaze_sweep(f360, gpu_ctx, oracle):
@@ -113,7 +115,7 @@ def test_walker_one_pass_rare_branches(f360, gpu_ctx, oracle, force):
 def test_band_switch_off_is_the_two_calls(f360, gpu_ctx, oracle):
     gpu_ctx.set_option("fuse.band", 0)
     try:
-        bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(f360, gpu_ctx, oracle, 640, 320, GAZES[:3]),
+        bad, kernels = _ran_band_writer(gpu_ctx, lambda: _run(f360, gpu_ctx, oracle, 640, 320, GAZES[:5]),
                                         calls=2)  # (the encode call and the sample call)
         assert bad == []
         assert "sat_write_fuse_kernel" not in kernels and "sample_rect_kernel" in kernels
