@@ -180,7 +180,7 @@ struct f360_ctx {
   int opt_interp_staged = 1;   // "interp.staged": the un-warp computes the vertical lerps once per reduced column (wave-private LDS) instead of per output pixel
   int opt_interp_rows = 0;     // "interp.rows": output rows per wave of the un-warp, 0 = by size
   int opt_r2y_rows = 0;        // "yuv.r2y_rows": chroma rows a wave of the RGB0 -> yuv420p converter walks down; 0 = by frame size (16 / 8 / 4, small frames: the kernel with one chroma row per thread), -1 = always that kernel
-  int opt_fuse_force = 0;      // "debug.fuse_force": tests only -- force the one-pass forms' rare branches (results stay exact): bit 0 = side rows of one pixel (more straddling boxes than they hold: the fix-up takes every row), bit 1 = no listed leftover rows (the fix-up finds them itself)
+  int opt_fuse_force = 0;      // "debug.fuse_force": tests only -- force the one-pass forms' rare branches (results stay exact): bit 0 = side rows of one pixel (more straddling boxes than they hold: the fix-up takes every row), bit 1 = no listed leftover rows (the fix-up finds them itself), bit 2 = the strip walker's helpers keep one round of pixels in registers and take their tail loop for the rest
   int opt_walk_spin = 0;       // "debug.walk_spin": polls a strip's hand-off wait may take before it finishes alone; 0 = 65536
   int opt_walk_mute = 0;       // "debug.walk_mute": test only -- unit (value - 1) of every read-once launch publishes no hand-off, so its right neighbour times out; 0 = none
   int opt_ablate = 0;          // "debug.ablate": timing experiments, breaks results

@@ -624,6 +624,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
     wf.pmax = pmax;
     wf.side_stride = side_stride;
     wf.lrows_max = lrows_max;
+    wf.force_tail = 0;
     wf.band_rows = band_rows;
     {
       f360::KernelSpan span(ctx, f360::kWalkFusePlan, prof, n);

@@ -58,6 +58,7 @@ int f360::sat_encode_sample_walk(f360_ctx *ctx, int count, uint32_t *const *sats
     wf.pmax = ws.pmax;
     wf.side_stride = ws.side_stride;
     wf.lrows_max = (ctx->opt_fuse_force & 2) ? 0 : kFixLrowsWalk;
+    wf.force_tail = (ctx->opt_fuse_force & 4) ? 1 : 0;
     wf.band_rows = 0;
     wf.ent = nullptr;
     {

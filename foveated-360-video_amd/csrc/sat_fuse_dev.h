@@ -50,6 +50,8 @@ struct WalkFuse {
   int pmax;
   size_t side_stride;  // dwords per frame
   int lrows_max;       // reduced rows the fix-up can take from a list (more: it takes every row)
+  int force_tail;      // tests ("debug.fuse_force" bit 2): a helper keeps ONE round of its pixels in
+                       // registers, the rest take the tail loop (else only strips of > 320 pixels do)
   // the band writer's one pass (sat_band_fuse.hip): rows per band, the per-strip pixel lists
   int band_rows;
   uint32_t *ent;  // [frame][strip][kBandEntStride]
@@ -338,7 +340,7 @@ __device__ __forceinline__ void walk_fuse_helper(const EncodeArgs &a, const Walk
 #define F360_FUSE_ROWS(NR)                                                                  \
   walk_fuse_rows<NR, PIX>(a, wf, plan, dst, lane, ent, n_ent, drows, mbox, max_dxw, xcol, xslot, \
                      npix, side, unit)
-  if (n_ent <= 64) F360_FUSE_ROWS(1);
+  if (n_ent <= 64 || wf.force_tail) F360_FUSE_ROWS(1);
   else if (n_ent <= 128) F360_FUSE_ROWS(2);
   else if (n_ent <= 192) F360_FUSE_ROWS(3);
   else if (n_ent <= 256) F360_FUSE_ROWS(4);

@@ -98,10 +98,11 @@ def test_band_one_pass_rare_branches(f360, gpu_ctx, oracle, force):
         gpu_ctx.set_option("debug.fuse_force", 0)
 
 
-@pytest.mark.parametrize("force", [1, 2, 3])
+@pytest.mark.parametrize("force", [1, 2, 3, 4, 7])
 def test_walker_one_pass_rare_branches(f360, gpu_ctx, oracle, force):
     """The same forced branches through the strip walker's one pass (the whole-row
-    fix-up and the unlisted-rows path were never exercised)."""
+    fix-up, the unlisted-rows path and -- bit 2 -- the helpers' tail loop for strips that own more
+    pixels than their registers hold were never exercised)."""
     gpu_ctx.set_option("debug.fuse_force", force)
     gpu_ctx.set_option("sat.walk", 1)
     try:
