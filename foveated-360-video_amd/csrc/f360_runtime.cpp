@@ -38,6 +38,13 @@ using f360::set_error;
 
 int f360::side_stream(f360_ctx *ctx) {
   if (ctx->side) return F360_OK;
+  {  // (creating a stream and events is not something to do inside a capture)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    F360_HIP_TRY(hipStreamIsCapturing(ctx->stream, &cap));
+    F360_REQUIRE(cap == hipStreamCaptureStatusNone,
+                 "the context's side stream must be created but the stream is being captured; "
+                 "run the same call once before the capture");
+  }
   F360_HIP_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   F360_HIP_TRY(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
   F360_HIP_TRY(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));

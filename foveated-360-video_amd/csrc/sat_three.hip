@@ -353,7 +353,17 @@ int ensure_plan(f360_ctx *ctx, int width, int height, bool planar = false, int f
     return F360_OK;
   }
   frames = std::max(frames, p.width == width && p.height == height ? p.frames : 1);
-  // A geometry change re-carves the scratch; wait for work that may use it.
+  // A geometry change (or more frames per launch group) re-carves the scratch: it allocates and
+  // waits for work that may use the old one -- both illegal while the stream is being captured
+  // into a graph, so say so instead of breaking the capture (warm up eagerly first).
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    F360_HIP_TRY(hipStreamIsCapturing(ctx->stream, &cap));
+    F360_REQUIRE(cap == hipStreamCaptureStatusNone,
+                 "f360_sat_encode: the encoder's scratch for %dx%d x %d frames must be allocated "
+                 "but the stream is being captured; run the same call once before the capture",
+                 width, height, frames);
+  }
   if (p.ws.p) F360_HIP_TRY(hipStreamSynchronize(ctx->stream));
   p.width = width;
   p.height = height;

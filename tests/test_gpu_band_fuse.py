@@ -200,3 +200,59 @@ def test_band_one_pass_8k_against_the_oracle(f360, gpu_ctx, oracle, n):
     for b in srcs + sats + reds:
         b.free()
     dec.close()
+
+
+def test_band_one_pass_replays_from_a_hip_graph(f360, oracle):
+    """A pipelined band one-pass call uses the context's side stream between its first and its
+    last kernel (fork after the plan kernel, join before the fix-up): captured into a graph it
+    must refuse to allocate under the capture, and -- warmed up eagerly -- replay to the oracle's
+    bytes, tables and reduced frames."""
+    import torch
+    dev = torch.device("cuda", 0)
+    w, h, n = 1536, 256, 6
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    host = [oracle.lcg_frame(w, h, 70 + k) for k in range(n)]
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        frames = torch.from_numpy(np.stack(host)).to(dev)
+        sats = torch.zeros((n, h, w, 3), dtype=torch.int32, device=dev)
+        reds = torch.zeros((n, rh, 4 * rw), dtype=torch.uint8, device=dev)
+    stream.synchronize()
+    ctx = f360.Context(0, stream=stream.cuda_stream)
+    dec = f360.SATDecoder(ctx)
+    dec.InitializeGrid(rw, rh, w, h)
+    gazes = [GAZES[k] for k in range(n)]
+    args = (rw, rh, 4 * rw, [sats[k].data_ptr() for k in range(n)],
+            [frames[k].data_ptr() for k in range(n)], w, h, 4 * w, gazes)
+    g = torch.cuda.CUDAGraph()
+    refused = False
+    with torch.cuda.graph(g, stream=stream):
+        try:
+            dec.EncodeSampleFramesGPU([reds[k].data_ptr() for k in range(n)], *args)
+        except f360.F360Error as e:
+            refused = "captured" in str(e)
+    assert refused
+    stream.synchronize()
+    ctx.profile_reset()
+    ctx.profile_arm(1)
+    dec.EncodeSampleFramesGPU([reds[k].data_ptr() for k in range(n)], *args)   # eager warm-up
+    ctx.finish()
+    assert "sat_write_fuse_kernel" in ctx.profile_read()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=stream):
+        dec.EncodeSampleFramesGPU([reds[k].data_ptr() for k in range(n)], *args)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    for rep in range(3):
+        reds.fill_(0x5A)
+        sats.fill_(-1)
+        stream.synchronize()
+        g2.replay()
+        stream.synchronize()
+        for k in range(n):
+            want_sat = oracle.sat_encode(host[k], w, h, 4 * w)
+            assert np.array_equal(sats[k].cpu().numpy().view(np.uint32), want_sat), (rep, k)
+            want = np.full((rh, 4 * rw), 0x5A, dtype=np.uint8)
+            oracle.satdec_sample_rect(want, rw, rh, 4 * rw, want_sat, w, h, grid, *gazes[k])
+            assert np.array_equal(reds[k].cpu().numpy(), want), (rep, k)
+    dec.close()
+    ctx.close()
