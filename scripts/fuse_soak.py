@@ -3,8 +3,11 @@ encoder forced on) against the two calls it replaces, byte for byte, on random g
 counts, gaze points (inside, on and beyond every edge), padded targets; a third of the calls from
 planar YUV 4:2:0 frames (both libswscale models); every call also through the no-table form
 (FoveateFramesRect[YUV420P]GPU):
-    python scripts/fuse_soak.py [seconds] [seed] [big]
-("big": frames of 2560x1280 to 7680x3840, up to 5 per call -- dozens of strips, thousands of rows)"""
+    python scripts/fuse_soak.py [seconds] [seed] [big | band | bandbig]
+("big": frames of 2560x1280 to 7680x3840, up to 5 per call -- dozens of strips, thousands of rows;
+"band" / "bandbig": the one-pass form of the three-kernel encoder's table writer instead
+(csrc/sat_band_fuse.hip: read-once encoder off, "fuse.band" 2 so that single frames take it too),
+RGB0 frames only, band height and the side stream drawn per call)"""
 import os
 import sys
 import time
@@ -14,13 +17,16 @@ import f360_amd as f360
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-big = len(sys.argv) > 3 and sys.argv[3] == "big"
+big = len(sys.argv) > 3 and sys.argv[3] in ("big", "bandbig")
+band = len(sys.argv) > 3 and sys.argv[3] in ("band", "bandbig")
 rng = np.random.default_rng(seed)
 t0 = last_note = time.time()
 calls = frames_done = bad = planar_cases = 0
 worst = []
 with f360.Context(0) as ctx:
-    ctx.set_option("sat.walk", 1)
+    ctx.set_option("sat.walk", 0 if band else 1)
+    if band:
+        ctx.set_option("fuse.band", 2)
     enc = f360.SATEncoder(ctx)
     while time.time() - t0 < budget:
         kind = rng.integers(0, 4) if not big else 9
@@ -36,6 +42,10 @@ with f360.Context(0) as ctx:
         else:
             w, h = 256 * int(rng.integers(1, 12)), 8 * int(rng.integers(1, 60))
         n = int(rng.integers(1, 14)) if not big else int(rng.integers(1, 6))
+        if band:
+            ctx.set_option("sat.band_rows", int(rng.choice([0, 0, 16, 32, 64])))
+            ctx.set_option("sat.pipeline", int(rng.integers(0, 2)))
+            ctx.set_option("debug.fuse_force", int(rng.choice([0, 0, 0, 1, 2, 3])))
         rw, rh = f360.reduced_size(w), f360.reduced_size(h)
         tpad = 4 * int(rng.integers(0, 5))
         tl = 4 * rw + tpad
@@ -69,7 +79,7 @@ with f360.Context(0) as ctx:
             b.fill(fill)
         for b in sats_b:
             b.fill(0xEE)
-        planar = h % 2 == 0 and rng.integers(0, 3) == 0  # a third of the cases from planes
+        planar = not band and h % 2 == 0 and rng.integers(0, 3) == 0  # a third of the cases from planes
         if planar:
             planar_cases += 1
             model = int(rng.integers(0, 2))
