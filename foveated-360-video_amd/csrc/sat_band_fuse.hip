@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void band_fuse_plan_kernel(const WalkFuse wf, 
 // flight between two of them, so the compiler may move or copy their results as it likes.
 __device__ __forceinline__ void band_emit_wide(uint32_t pr, uint8_t *orow, uint32_t dlds,
                                                uint32_t elds, int lane, int n_ent, u32x2 e0,
-                                               uint32_t max_dxw, bool no_px) {
+                                               u32x2 es1, u32x2 h01, uint32_t h2, u32x2 l01,
+                                               uint32_t l2, uint32_t max_dxw, bool no_px) {
   const uint32_t dy = (pr >> 16) & 0x3ffu;
   const bool quick = dy * max_dxw <= 2048u;  // the float quotient is exact (tests/test_fuse_div.py)
   const float inv_dy = __builtin_amdgcn_rcpf((float)dy);
@@ -214,9 +215,9 @@ __device__ __forceinline__ void band_emit_wide(uint32_t pr, uint8_t *orow, uint3
   for (int b0 = 0; b0 < n_ent; b0 += 64) {
     const uint32_t eoff = es.x, estore = es.y;
     const bool valid = b0 + lane < n_ent;
-    u32x2 h01, l01;
-    uint32_t h2, l2;
-    if (b0 + 64 < n_ent) {  // (wave-uniform) the next round's entry along with this round's gathers
+    if (b0 == 0) {
+      es = es1;  // (round 0's gathers and round 1's entries came with the caller's exchange)
+    } else if (b0 + 64 < n_ent) {  // (wave-uniform) the next round's entry along with the gathers
       asm volatile(
           "ds_read_b64 %0, %5\n\t"
           "ds_read2_b32 %1, %6 offset1:1\n\t"
@@ -439,8 +440,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
         // (1) boxes one column wide, from registers: a lane has both of their columns, or takes
         // the left one from its neighbour (the first column of a strip never ends such a box:
         // its left column lies in the other strip)
-        if (any_unit && !(a.ablate & 2048)) {
-          uint32_t mypx[4];  // columns 4 * lane + k, packed R | G << 8 | B << 16
+        const bool do_unit = any_unit && !(a.ablate & 2048);
+        const bool do_wide = needs_d && !(a.ablate & 4096);
+        uint32_t mypx[4] = {0, 0, 0, 0};  // columns 4 * lane + k, packed R | G << 8 | B << 16
+        if (do_unit) {
           if (dy == 1u) {  // the fovea: a reduced pixel IS a source pixel
 #pragma unroll
             for (int k = 0; k < 4; ++k) mypx[k] = px[k];
@@ -471,42 +474,57 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
               mypx[k] = q[0] | (q[1] << 8) | (q[2] << 16);
             }
           }
-          // turn the row segment around: in as column 4 * lane + k, out as column lane + 64 k
-          u32x2 t01, t23;
-          asm volatile(
-              "ds_write_b128 %2, %3\n\t"
-              "ds_read2st64_b32 %0, %4 offset1:1\n\t"
-              "ds_read2st64_b32 %1, %4 offset0:2 offset1:3\n\t"
-              "s_waitcnt lgkmcnt(0)"
-              : "=&v"(t01), "=&v"(t23)
-              : "v"(tlds + lane * 16), "v"(u32x4{mypx[0], mypx[1], mypx[2], mypx[3]}),
-                "v"(tlds + lane * 4)
-              : "memory");
-          const uint32_t out[4] = {t01.x, t01.y, t23.x, t23.y};
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (ux[k] != kNoPixel && !no_px) band_store_px(orow, ux[k], out[k], a.ablate & 16384);
         }
-        // (2) wider boxes and the columns of boxes that straddle two strips: D row through the
-        // staging slice (its reads have returned)
-        if (needs_d && !(a.ablate & 4096)) {
+        // (2) wider boxes and the columns of boxes that straddle two strips need the D row: into
+        // the staging slice (its reads have returned)
+        if (do_wide) {
           lds_write_b128(mine + lane * 48, u32x4{acc[0] - snap[0], acc[1] - snap[1],
                                                   acc[2] - snap[2], acc[3] - snap[3]});
           lds_write_b128(mine + lane * 48 + 16, u32x4{acc[4] - snap[4], acc[5] - snap[5],
                                                        acc[6] - snap[6], acc[7] - snap[7]});
           lds_write_b128(mine + lane * 48 + 32, u32x4{acc[8] - snap[8], acc[9] - snap[9],
                                                        acc[10] - snap[10], acc[11] - snap[11]});
-          if (n_ent > 0) band_emit_wide(pr, orow, mine, elds, lane, n_ent, e0, max_dxw, no_px);
-          if (exports) {
-            u32x2 x01[3];
-            uint32_t x2[3];
+        }
+        // ONE LDS round trip for everything the row needs back (they were five in a row: the
+        // turned-around row, the wide boxes' first round, three straddling columns): the row of
+        // one-column boxes goes in and comes back as columns lane + 64 k, the first 64 wide boxes
+        // gather their two columns, the second round's entries and the straddling columns come
+        // along.  Paths that are off read slots nobody looks at.  One statement, one wait.
+        u32x2 t01, t23, h01, l01, es1, x01[3];
+        uint32_t h2, l2, x2[3];
+        asm volatile(
+            "ds_write_b128 %13, %14\n\t"
+            "ds_read2st64_b32 %0, %15 offset1:1\n\t"
+            "ds_read2st64_b32 %1, %15 offset0:2 offset1:3\n\t"
+            "ds_read2_b32 %2, %16 offset1:1\n\t"
+            "ds_read_b32 %3, %16 offset:8\n\t"
+            "ds_read2_b32 %4, %17 offset1:1\n\t"
+            "ds_read_b32 %5, %17 offset:8\n\t"
+            "ds_read_b64 %6, %18\n\t"
+            "ds_read2_b32 %7, %19 offset1:1\n\t"
+            "ds_read_b32 %8, %19 offset:8\n\t"
+            "ds_read2_b32 %9, %20 offset1:1\n\t"
+            "ds_read_b32 %10, %20 offset:8\n\t"
+            "ds_read2_b32 %11, %21 offset1:1\n\t"
+            "ds_read_b32 %12, %21 offset:8\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(t01), "=&v"(t23), "=&v"(h01), "=&v"(h2), "=&v"(l01), "=&v"(l2), "=&v"(es1),
+              "=&v"(x01[0]), "=&v"(x2[0]), "=&v"(x01[1]), "=&v"(x2[1]), "=&v"(x01[2]), "=&v"(x2[2])
+            : "v"(tlds + lane * 16), "v"(u32x4{mypx[0], mypx[1], mypx[2], mypx[3]}),
+              "v"(tlds + lane * 4), "v"(mine + (e0.x & 0xfffu)), "v"(mine + ((e0.x >> 12) & 0xfffu)),
+              "v"(elds + (uint32_t)(64 + lane) * 8u), "v"(mine + (uint32_t)xcol[0] * 12u),
+              "v"(mine + (uint32_t)xcol[1] * 12u), "v"(mine + (uint32_t)xcol[2] * 12u)
+            : "memory");
+        if (do_unit) {
+          const uint32_t out[4] = {t01.x, t01.y, t23.x, t23.y};
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-              asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\t"
-                           "s_waitcnt lgkmcnt(0)"
-                           : "=&v"(x01[k]), "=&v"(x2[k])
-                           : "v"(mine + (uint32_t)xcol[k] * 12u)
-                           : "memory");
+          for (int k = 0; k < 4; ++k)
+            if (ux[k] != kNoPixel && !no_px) band_store_px(orow, ux[k], out[k], a.ablate & 16384);
+        }
+        if (do_wide) {
+          if (n_ent > 0)
+            band_emit_wide(pr, orow, mine, elds, lane, n_ent, e0, es1, h01, h2, l01, l2, max_dxw, no_px);
+          if (exports) {
             uint32_t *srow = side + (size_t)(pr & 0xffffu) * npix * 6;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -514,8 +532,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
                 asm volatile("global_store_dwordx3 %0, %1, %2" ::"v"((uint32_t)xslot[k] * 12u),
                              "v"(u32x3v{x01[k].x, x01[k].y, x2[k]}), "s"(srow)
                              : "memory");
-          } else {
-            // (the gathers above ended with their own wait; the next row's staging may follow)
           }
         }
       }
