@@ -1,7 +1,9 @@
-// sat_band_fuse.hip -- encode + sample in one pass for calls too small for the strip walker:
-// one frame (the per-frame loop of the reference's offline tool, run_satlogrectilinear.cc:926-938,
-// where the gaze comes from a trace before the encode) up to the 22 8K frames below
-// "sat.walk_units" (8 per rank when BASELINE config 4's 64 frames are sharded over 8 GPUs).
+// sat_band_fuse.hip -- encode + sample in one pass for calls too small for the strip walker: up
+// to the 22 8K frames below "sat.walk_units" (8 per rank when BASELINE config 4's 64 frames are
+// sharded over 8 GPUs).  Taken from four frames per call on ("fuse.band" 1); a call of one to
+// three frames -- the per-frame loop of the reference's offline tool,
+// run_satlogrectilinear.cc:926-938 -- is faster as the two calls and stays that unless
+// "fuse.band" is 2 (profiles/round5_band_one_pass.txt).
 //
 // The three-kernel encoder's table writer (sat_three.hip: one wave per band x strip tile) holds,
 // at every row of its tile, the table row of its strip in registers -- exactly what a strip owner

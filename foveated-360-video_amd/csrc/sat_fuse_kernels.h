@@ -19,6 +19,7 @@ namespace sat {
 //     frame's last table row).
 // Such rows get their marks -- EMIT | j | height at hi, SNAP at lo -- and every other processed
 // row is left to walk_fuse_fix_kernel, which recognises it by the missing mark.
+// (a template only so that the header can be included by several translation units)
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void walk_fuse_plan_kernel(const int16_t *__restrict__ gy,
                                                              int out_h, int src_w, int src_h,

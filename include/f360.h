@@ -225,10 +225,14 @@ int f360_satdec_sample_rect_frames(f360_sat_decoder *dec, uint8_t *const *target
  * (src/video_server.cc:296-303,324-328,336), so using this call there changes its control flow
  * -- it keeps the two calls.  Table k of source k AND reduced frame k at
  * gaze k, byte for byte what f360_sat_encode_batch followed by f360_satdec_sample_rect_frames
- * write.  With enough frames for the read-once encoder (f360_sat_encode_batch's rule; RGB0
- * sources) the reduced pixels are produced during the encoder's pass, from table rows still in
- * registers, and the tables are not read back; otherwise this IS the two calls.  All arrays are
- * HOST arrays.  Not in the reference. */
+ * write.  The reduced pixels are produced during the encoder's pass, from table rows still in
+ * registers, and the tables are not read back: by the read-once encoder's strip owners with
+ * enough frames to fill the device (f360_sat_encode_batch's rule: 23 8K frames), by the
+ * three-kernel encoder's table writer for 4 .. 22 (RGB0 frames; "fuse.band"); a call of 1 .. 3
+ * frames, or one whose sources the encoders' fast paths do not take, IS the two calls.  A call on
+ * the three-kernel encoder runs its launch groups on two streams between its first and its last
+ * kernel ("sat.pipeline"); from outside it is work enqueued on the context's one in-order stream.
+ * All arrays are HOST arrays.  Not in the reference. */
 int f360_satdec_encode_sample_frames(f360_sat_decoder *dec, uint8_t *const *targets_dev,
                                      uint32_t *const *sats_dev,
                                      const uint8_t *const *sources_dev, int count,
