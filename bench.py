@@ -156,7 +156,7 @@ def one_pass_plan(args, frames_per_call):
         if o.get("fuse.walk", "1") != "0":
             return "strip walker (sat_walk_kernel<.., true>)"
     band = int(o.get("fuse.band", "1"))
-    if (band == 2 or (band == 1 and frames_per_call >= 4)) and args.source == "rgb0":
+    if band == 2 or (band == 1 and frames_per_call >= 4):
         return "band writer (sat_write_fuse_kernel)"
     return "two calls inside the library"
 
@@ -843,7 +843,7 @@ def main():
                   "two calls) and run_satlogrectilinear.cc:926-938")
             one_pass_opts = dict(kv.split("=") for kv in args.opt)
             shape("per_frame_one_pass", per_frame_one_pass, 3,
-                  one_pass_bytes if one_pass_opts.get("fuse.band", "1") == "2" and not yuv else survey_path_bytes,
+                  one_pass_bytes if one_pass_opts.get("fuse.band", "1") == "2" else survey_path_bytes,
                   "the offline tool with its two calls merged into one (trace gaze known before the "
                   "encode, run_satlogrectilinear.cc:932-938); not the server")
             if fpc > 1:

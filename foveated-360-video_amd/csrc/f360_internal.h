@@ -358,12 +358,13 @@ int side_stream(f360_ctx *ctx);
 // Makes the three-kernel encoder's scratch hold `frames` slices of this geometry (sat_three.hip).
 
 // The same for calls the read-once encoder does not take (1 .. 22 8K frames): the three-kernel
-// encoder with its table writer in one-pass form (sat_band_fuse.hip); RGB0 frames.
+// encoder with its table writer in one-pass form (sat_band_fuse.hip); RGB0 frames or planes.
 bool sat_encode_sample_band_applies(const f360_ctx *ctx, int count, int width, int height,
-                                    int linesize, int out_w, int out_h, int dst_linesize);
+                                    int linesize, int out_w, int out_h, int dst_linesize,
+                                    const YuvPlanes *yuv = nullptr);
 int sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats,
-                           const uint8_t *const *srcs, int width, int height, int linesize,
-                           const SatFuse &fuse, bool prof);
+                           const uint8_t *const *srcs, const YuvPlanes *yuvs, int width, int height,
+                           int linesize, const SatFuse &fuse, bool prof);
 }  // namespace f360
 
 struct f360_event {

@@ -263,7 +263,7 @@ __device__ __forceinline__ void band_emit_wide(uint32_t pr, uint8_t *orow, uint3
 template <int SRC>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
     const EncodeArgs a, const EncodeBatch eb, const WalkFuse wf, int frame0) {
-  static_assert(SRC == kSrcRgb0, "the band writer's one pass takes RGB0 frames");
+  static_assert(SRC != kSrcBytes, "the band writer's one pass takes aligned RGB0 frames or planes");
   // per wave: 3 KiB store staging / D row, 1 KiB to turn a row of reduced pixels around (below),
   // then the strip's list of wide boxes past the first round (8 bytes each; 6 KiB, hardly ever
   // used)
@@ -556,10 +556,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sat_write_fuse_kernel(
 // The table writer's launch of a three-kernel encode (sat_three.hip: sat_encode_impl), one-pass
 // form.  `grid` / frames as for sat_write_kernel.
 void f360::sat::launch_write_fuse(f360_ctx *ctx, hipStream_t stream, const EncodeArgs &a,
-                                  const EncodeBatch &eb, dim3 grid, const f360::SatBandFuse &bf) {
+                                  const EncodeBatch &eb, dim3 grid, const f360::SatBandFuse &bf,
+                                  int src_kind) {
   (void)ctx;
-  hipLaunchKernelGGL((sat_write_fuse_kernel<kSrcRgb0>), grid, dim3(64 * kWavesPerBlock), 0, stream,
-                     a, eb, bf.wf, bf.frame0);
+  const dim3 block(64 * kWavesPerBlock);
+  if (src_kind == kSrcYuvSwsX86)
+    hipLaunchKernelGGL((sat_write_fuse_kernel<kSrcYuvSwsX86>), grid, block, 0, stream, a, eb, bf.wf, bf.frame0);
+  else if (src_kind == kSrcYuvSwsC)
+    hipLaunchKernelGGL((sat_write_fuse_kernel<kSrcYuvSwsC>), grid, block, 0, stream, a, eb, bf.wf, bf.frame0);
+  else
+    hipLaunchKernelGGL((sat_write_fuse_kernel<kSrcRgb0>), grid, block, 0, stream, a, eb, bf.wf, bf.frame0);
 }
 
 // Whether f360_satdec_encode_sample_frames can take the band writer's one pass for this call
@@ -572,8 +578,15 @@ static size_t band_plan_lds_bytes(int width, int height, int out_w, int out_h) {
   return band_plan_lds_bytes(height, out_w, out_h) + (size_t)((width + kStripPx - 1) / kStripPx) * 1024;
 }
 bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int count, int width, int height,
-                                          int linesize, int out_w, int out_h, int dst_linesize) {
-  return (ctx->opt_fuse_band == 2 || (ctx->opt_fuse_band == 1 && count >= 4)) && linesize / width == 4 && linesize % 16 == 0 &&
+                                          int linesize, int out_w, int out_h, int dst_linesize,
+                                          const f360::YuvPlanes *yuv) {
+  // the source side: f360_sat_encode_batch's / f360_sat_encode_yuv420p_batch's own fast-path rules
+  const bool source_ok =
+      yuv ? height % 2 == 0 && yuv->y_linesize >= width && yuv->u_linesize >= width / 2 &&
+                yuv->v_linesize >= width / 2 && yuv->y_linesize % 4 == 0 &&
+                yuv->u_linesize % 2 == 0 && yuv->v_linesize % 2 == 0
+          : linesize / width == 4 && linesize % 16 == 0;
+  return (ctx->opt_fuse_band == 2 || (ctx->opt_fuse_band == 1 && count >= 4)) && source_ok &&
          width % 4 == 0 && width <= f360::kMaxDim &&
          (size_t)width * height * 3 < ((size_t)1 << 31) && out_w < 65536 && out_h < 65536 &&
          (width + kStripPx - 1) / kStripPx <= kFixCols / 4 && dst_linesize % 4 == 0 &&
@@ -585,19 +598,19 @@ bool f360::sat_encode_sample_band_applies(const f360_ctx *ctx, int count, int wi
 // launch per (up to kWalkFrames) frames, between them the encoder's launches of "sat.batch_mb"
 // each -- reducer, carry pass, and the table writer in its one-pass form.
 int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats,
-                                 const uint8_t *const *srcs, int width, int height, int linesize,
-                                 const f360::SatFuse &fuse, bool prof) {
+                                 const uint8_t *const *srcs, const f360::YuvPlanes *yuvs, int width,
+                                 int height, int linesize, const f360::SatFuse &fuse, bool prof) {
   f360::SatEncodePlan &p = ctx->enc;
   const int nstrips = (width + kStripPx - 1) / kStripPx;
   const int plan_stride = ((height + kRowUnroll - 1) / kRowUnroll) * kRowUnroll;
   const int pmax = (ctx->opt_fuse_force & 1) ? 1 : std::max(1, std::min(3 * (nstrips - 1), kFixCols));
   const size_t side_stride = ((size_t)fuse.out_h * pmax * 6 + 3) & ~(size_t)3;  // dwords per frame
-  const size_t frame_bytes = (size_t)linesize * height;
+  const size_t frame_bytes = yuvs ? (size_t)yuvs[0].y_linesize * height * 3 / 2 : (size_t)linesize * height;
   const int per_launch = (int)std::min<size_t>(
       std::max<size_t>(((size_t)std::max(ctx->opt_batch_mb, 1) << 20) / frame_bytes, 1),
       (size_t)kEncBatch);
   // (the band height is the encoder plan's: make sure it exists before the plan kernel runs)
-  int st = f360_sat_encode_prepare(ctx, width, height);
+  int st = f360::sat_encode_reserve(ctx, width, height, std::min(per_launch, count), yuvs != nullptr);
   if (st != F360_OK) return st;
   const int band_rows = p.band_rows, nbands = (height + band_rows - 1) / band_rows;
   // reduced rows the plan cannot mark: one per band boundary at most, plus the clamped edge rows
@@ -622,7 +635,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
     f360::SatBandFuse bf;
     WalkFuse &wf = bf.wf;
     WalkBatch wb;
-    walk_fill_batch(wb, c0, n, sats, srcs, nullptr);
+    walk_fill_batch(wb, c0, n, sats, srcs, yuvs);
     for (int k = 0; k < kWalkFrames; ++k) {
       const int q = c0 + (k < n ? k : 0);
       wf.dst[k] = fuse.dsts[q];
@@ -653,13 +666,13 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
     // (launch groups alternate between the context's stream and its side stream, see
     // sat_pipelined_groups: forked after the plan kernel, joined before the fix-up)
     st = f360::sat_pipelined_groups(
-        ctx, width, height, false, (n + per_launch - 1) / per_launch, std::min(per_launch, n), true,
+        ctx, width, height, yuvs != nullptr, (n + per_launch - 1) / per_launch, std::min(per_launch, n), true,
         [&](int g, const f360::SatLaunch &where) {
           const int k0 = g * per_launch, m = std::min(n - k0, per_launch);
           bf.frame0 = k0;
           const int e = f360::sat_encode_impl(ctx, nullptr, nullptr, width, height, linesize, nullptr,
-                                              nullptr, m, sats + c0 + k0, srcs + c0 + k0,
-                                              prof ? 1 : 0, nullptr, &bf, &where);
+                                              nullptr, m, sats + c0 + k0, srcs ? srcs + c0 + k0 : nullptr,
+                                              prof ? 1 : 0, yuvs ? yuvs + c0 + k0 : nullptr, &bf, &where);
           if (e == F360_OK && ctx->enc.band_rows != band_rows) {  // (cannot happen: same geometry)
             f360::set_error("f360_satdec_encode_sample_frames: the encoder plan changed under the call");
             return (int)F360_ERR_INVALID_ARG;
@@ -674,6 +687,7 @@ int f360::sat_encode_sample_band(f360_ctx *ctx, int count, uint32_t *const *sats
                                   std::max(lrows_max, 1) * ((wf.out_w + 255) / 256), n),
                          dim3(256), 0, ctx->stream, wb, wf, width, height, linesize, -1,
                          f360::YuvPlanes{nullptr, nullptr, nullptr, 0, 0, 0}, f360::YuvConsts{});
+      // (tables are always written on this path, so the fix-up samples them whatever the source)
     }
   }
   F360_HIP_TRY(hipGetLastError());

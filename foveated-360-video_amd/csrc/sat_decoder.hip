@@ -1301,10 +1301,10 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
                      f360::sat_encode_sample_applies(ctx, count, source_width, source_height,
                                                      source_linesize, target_width, target_height,
                                                      target_linesize, planes);
-  const bool bands = !walks && !planes && sats_dev &&
+  const bool bands = !walks && sats_dev &&
                      f360::sat_encode_sample_band_applies(ctx, count, source_width, source_height,
                                                           source_linesize, target_width,
-                                                          target_height, target_linesize);
+                                                          target_height, target_linesize, planes);
   bool one_pass = walks || bands;
   for (int k = 0; k < count && one_pass; ++k) {
     one_pass = targets_dev[k] && (!sats_dev || (sats_dev[k] && ((uintptr_t)sats_dev[k] % 16) == 0)) &&
@@ -1341,7 +1341,7 @@ static int encode_sample_frames_impl(f360_sat_decoder *dec, uint8_t *const *targ
                              dec->gy_dev.as<int16_t>(), target_width, target_height,
                              target_linesize};
     if (bands)
-      return f360::sat_encode_sample_band(ctx, count, sats_dev, sources_dev, source_width,
+      return f360::sat_encode_sample_band(ctx, count, sats_dev, sources_dev, planes, source_width,
                                           source_height, source_linesize, fuse,
                                           f360::take_profile_slot(ctx));
     return f360::sat_encode_sample_walk(ctx, count, sats_dev, sources_dev, planes, source_width,

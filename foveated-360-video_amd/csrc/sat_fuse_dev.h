@@ -77,7 +77,7 @@ struct SatBandFuse {
 };
 namespace sat {
 void launch_write_fuse(f360_ctx *ctx, hipStream_t stream, const EncodeArgs &a,
-                       const EncodeBatch &eb, dim3 grid, const f360::SatBandFuse &bf);
+                       const EncodeBatch &eb, dim3 grid, const f360::SatBandFuse &bf, int src_kind);
 template <bool FUSE> struct WalkFuseArg { typedef WalkNoFuse type; };
 template <> struct WalkFuseArg<true> { typedef WalkFuse type; };
 

@@ -558,11 +558,12 @@ int sat_encode_impl(f360_ctx *ctx, uint32_t *sat_dev, const uint8_t *src_dev, in
                        stream, sa, sb, sc, p.ws_stride);
   }
   if (band_fuse) {  // the writer also emits the reduced pixels of its tile (sat_band_fuse.hip)
-    F360_REQUIRE(vec && !emit && count > 0, "sat_encode_impl: the one-pass writer takes batches of aligned RGB0 frames");
+    F360_REQUIRE((vec || yuv_src) && !emit && count > 0,
+                 "sat_encode_impl: the one-pass writer takes batches of aligned RGB0 frames or planes");
     f360::KernelSpan span(ctx, f360::kSatWriteFuse, prof, (int)frames, stream);
     launch_write_fuse(ctx, stream, a, eb,
                       dim3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock, frames),
-                      *band_fuse);
+                      *band_fuse, yuv_src ? yuv_src : kSrcRgb0);
   } else {
     f360::KernelSpan span(ctx, f360::kSatWrite, prof, (int)frames, stream);
     const dim3 grid3((p.nstrips * p.nbands + kWavesPerBlock - 1) / kWavesPerBlock, frames);

@@ -7,7 +7,7 @@ planar YUV 4:2:0 frames (both libswscale models); every call also through the no
 ("big": frames of 2560x1280 to 7680x3840, up to 5 per call -- dozens of strips, thousands of rows;
 "band" / "bandbig": the one-pass form of the three-kernel encoder's table writer instead
 (csrc/sat_band_fuse.hip: read-once encoder off, "fuse.band" 2 so that single frames take it too),
-RGB0 frames only, band height and the side stream drawn per call)"""
+band height and the side stream drawn per call)"""
 import os
 import sys
 import time
@@ -79,7 +79,7 @@ with f360.Context(0) as ctx:
             b.fill(fill)
         for b in sats_b:
             b.fill(0xEE)
-        planar = not band and h % 2 == 0 and rng.integers(0, 3) == 0  # a third of the cases from planes
+        planar = h % 2 == 0 and rng.integers(0, 3) == 0  # a third of the cases from planes
         if planar:
             planar_cases += 1
             model = int(rng.integers(0, 2))

@@ -256,3 +256,50 @@ def test_band_one_pass_replays_from_a_hip_graph(f360, oracle):
             assert np.array_equal(reds[k].cpu().numpy(), want), (rep, k)
     dec.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("w,h,n", [(1024, 512, 6), (1336, 202, 5), (3840, 1920, 4)])
+def test_band_one_pass_from_planes(f360, gpu_ctx, oracle, w, h, n, model):
+    """The decoder's planar YUV 4:2:0 frames through the band writer's one pass
+    (EncodeSampleFramesYUV420PGPU with 4 .. 22 frames): tables and reduced frames equal the oracle's
+    on the RGB0 frame its libswscale restatement makes of the same planes, both rounding models."""
+    rw, rh = f360.reduced_size(w), f360.reduced_size(h)
+    grid = oracle.satdec_grid(rw, rh, w, h)
+    gpu_ctx.set_option("yuv.model", model)
+    try:
+        dec = f360.SATDecoder(gpu_ctx)
+        dec.InitializeGrid(rw, rh, w, h)
+        planes = [(oracle.lcg_frame(w, h, 600 + k, bpp=1), oracle.lcg_frame(w // 2, h // 2, 700 + k, bpp=1),
+                   oracle.lcg_frame(w // 2, h // 2, 800 + k, bpp=1)) for k in range(n)]
+        planes[0] = tuple(np.full_like(p, 255) for p in planes[0])
+        bufs = [tuple(gpu_ctx.upload(p.reshape(-1)) for p in planes[k]) for k in range(n)]
+        sats = [gpu_ctx.malloc(w * h * 12) for _ in range(n)]
+        reds = [gpu_ctx.malloc(rw * rh * 4) for _ in range(n)]
+        for b in sats:
+            b.fill(0xEE)
+        for b in reds:
+            b.fill(0x5A)
+        gazes = GAZES[:n]
+        gpu_ctx.profile_reset()
+        gpu_ctx.profile_arm(1)
+        dec.EncodeSampleFramesYUV420PGPU([b.ptr for b in reds], rw, rh, 4 * rw, [b.ptr for b in sats],
+                                         [tuple(b.ptr for b in bufs[k]) for k in range(n)], w, w // 2, w // 2,
+                                         w, h, gazes)
+        gpu_ctx.finish()
+        assert "sat_write_fuse_kernel" in gpu_ctx.profile_read()
+        for k in range(n):
+            frame = oracle.yuv420p_to_rgb0(*planes[k], w, h, model)
+            want_sat = oracle.sat_encode(frame.reshape(-1), w, h, 4 * w)
+            assert np.array_equal(sats[k].copy_to_host(np.uint32, (h, w, 3)), want_sat), (k, "table")
+            want = np.full((rh, 4 * rw), 0x5A, dtype=np.uint8)
+            oracle.satdec_sample_rect(want, rw, rh, 4 * rw, want_sat, w, h, grid, *gazes[k])
+            assert np.array_equal(reds[k].copy_to_host(np.uint8, (rh, 4 * rw)), want), (k, gazes[k])
+        for group in bufs:
+            for b in group:
+                b.free()
+        for b in sats + reds:
+            b.free()
+        dec.close()
+    finally:
+        gpu_ctx.set_option("yuv.model", 1)
