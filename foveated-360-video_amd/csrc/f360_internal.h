@@ -170,7 +170,7 @@ struct f360_ctx {
   int opt_sb_bands = -1;       // "sat.sb_bands": bands per reducer wave (-1: 1 for planar sources and 64-row bands, else 2; 0: as few super-bands as 32)
   int opt_sample_variant = 2;  // "sample.variant": 0 per-pixel, 1 column walker, 2 tile streamer (falls back to the walker where it does not apply)
   int opt_walk_rows = 8;       // "sample.rows": reduced rows per wave of the column walker
-  int opt_stream_rows = 0;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64; 0 = by size (4 for a single small frame, else 8)
+  int opt_stream_rows = 0;     // "sample.srows": reduced rows per wave of the tile streamer, <= 64; 0 = 4 for a single frame's launch, 8 for the batched launches
   int opt_sample_fpl = 16;     // "sample.fpl": frames per launch of f360_satdec_sample_rect_frames (1..64)
   int opt_batch_mb = 180;      // "sat.batch_mb": source bytes (MB) a batched encoder launch may cover
   int opt_walk = -1;           // "sat.walk": batched encodes read the frame once (sat_walk_kernel): -1 = when the batch fills the device ("sat.walk_units"), 0 never, 1 whenever the layout allows

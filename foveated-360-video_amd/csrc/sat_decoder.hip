@@ -1129,12 +1129,11 @@ int f360_satdec_sample_rect(f360_sat_decoder *dec, uint8_t *target_dev,
   if (variant == 2 && can_stream) {
     const int ntiles = (source_width + kTsTile - 1) / kTsTile;
     if (fits) {
-      // reduced rows per wave ("sample.srows", 0 = by size): a single small frame cannot fill
-      // the device with 8-row runs (1080p -> 608 rows: 76 runs x 15 tiles), 4-row runs double
-      // the waves (13.6 -> 11.7 us at 1080p, 15.1 -> 14.2 at 2560x1440, nothing at 3840x1920)
-      const int rows = std::min(ctx->opt_stream_rows > 0 ? ctx->opt_stream_rows
-                                : (long)target_height * ((source_width + kTsTile - 1) / kTsTile) < 20000 ? 4 : 8,
-                                kTsMaxRows);
+      // reduced rows per wave ("sample.srows", 0 = 4): a single frame's launch has nothing else
+      // to overlap its waves' set-up with, so shorter runs -- more waves -- pay at every size
+      // (4 against 8 rows: 13.6 -> 11.7 us at 1080p, 15.1 -> 14.2 at 2560x1440, 53.4 -> 51.5 at
+      // 8K, round 5; 12 rows 56.6, 16 rows 59.7); the batched launches keep 8
+      const int rows = std::min(ctx->opt_stream_rows > 0 ? ctx->opt_stream_rows : 4, kTsMaxRows);
       const int nblocks = (target_height + rows - 1) / rows;
       // (a ring of 3 slots: two table rows in flight; rings of 4 and 6, a tile order spread over
       // the XCDs and 16-byte group stores were A/B switches until round 4: EXPERIMENTS.md 3)
